@@ -1,0 +1,1072 @@
+// scene_host.cpp — host front-end of the render path: parses the reference's XML scene
+// schema, loads OBJ meshes / textures, builds the cyBVH-compatible
+// hierarchy and flattens everything into the blob the HIP kernels consume.
+//
+// Written from scratch; behaviour follows (all relative to /root/reference/BHRayTracer):
+//   xmlload.cpp:65-132   LoadScene       :172-271 LoadNode      :275-303 LoadTransform
+//   xmlload.cpp:307-390  LoadMaterial    :394-474 LoadLight     :478-521 ReadVector/Color/Float
+//   xmlload.cpp:525-582  ReadTexture     Scenes/scene.h:229-232 Transformation::Scale/Rotate/Translate
+//   Objects/TriObj/cyTriMesh.h:263-547 OBJ/MTL rules, :229-261 bbox + normals
+//   DataStructure/cyBVH.h:122-142,242-328 BVH build    Main.cpp:116-123,179-192 lights sort, camera frame
+// Compile with -ffp-contract=off: transforms, normals and BVH bounds must be bit-identical
+// to the reference's (they decide hit indices).
+#include "scene_host.h"
+
+#include <ctype.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+
+#include "mini_xml.h"
+#include "png_io.h"
+#include "vecmath.h"
+
+namespace bhrt {
+
+// ------------------------------------------------------------------------------------------------
+// Transformation (scene.h:208-246) on the host
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Mat3 {
+    float c[9];
+};
+Mat3 MatIdentity() { Mat3 m = {{1, 0, 0, 0, 1, 0, 0, 0, 1}}; return m; }
+// cyMatrix.h:671-681: per result column i: a = col0*r[i], b = col1*r[i+1], c = col2*r[i+2]; rd = a+b+c
+Mat3 MatMul(const Mat3 &l, const Mat3 &r)
+{
+    Mat3 o;
+    for (int i = 0; i < 9; i += 3)
+        for (int j = 0; j < 3; j++) {
+            float a = l.c[j] * r.c[i], b = l.c[3 + j] * r.c[i + 1], c = l.c[6 + j] * r.c[i + 2];
+            o.c[i + j] = a + b + c;
+        }
+    return o;
+}
+// cyMatrix.h:799-819
+Mat3 MatInverse(const Mat3 &m)
+{
+    const float *c = m.c;
+    Mat3 inv;
+    inv.c[0] = (c[4] * c[8] - c[5] * c[7]);
+    inv.c[1] = (c[2] * c[7] - c[1] * c[8]);
+    inv.c[2] = (c[1] * c[5] - c[2] * c[4]);
+    inv.c[3] = (c[5] * c[6] - c[3] * c[8]);
+    inv.c[4] = (c[0] * c[8] - c[2] * c[6]);
+    inv.c[5] = (c[2] * c[3] - c[0] * c[5]);
+    inv.c[6] = (c[3] * c[7] - c[4] * c[6]);
+    inv.c[7] = (c[1] * c[6] - c[0] * c[7]);
+    inv.c[8] = (c[0] * c[4] - c[1] * c[3]);
+    float det = c[0] * inv.c[0] + c[1] * inv.c[3] + c[2] * inv.c[6];
+    for (int i = 0; i < 9; i++) inv.c[i] /= det;
+    return inv;
+}
+
+struct Xform {
+    Mat3 tm = MatIdentity(), itm = MatIdentity();
+    V3 pos = {0, 0, 0};
+    void Transform(const Mat3 &m) // scene.h:232
+    {
+        tm = MatMul(m, tm);
+        pos = mat_mul(m.c, pos);
+        itm = MatInverse(tm);
+    }
+    void Scale(float sx, float sy, float sz) // scene.h:231
+    {
+        Mat3 m = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+        m.c[0] = sx; m.c[4] = sy; m.c[8] = sz;
+        Transform(m);
+    }
+    void Rotate(V3 axis, float degrees) // scene.h:230 + cyMatrix.h:522-533
+    {
+        float angle = degrees * (float)M_PI / 180.0f;
+        float sinAngle = sinf(angle), cosAngle = cosf(angle);
+        float t = 1.0f - cosAngle;
+        V3 a = t * axis;
+        float txy = a.x * axis.y, txz = a.x * axis.z, tyz = a.y * axis.z;
+        V3 s = sinAngle * axis;
+        Mat3 m;
+        m.c[0] = a.x * axis.x + cosAngle; m.c[1] = txy + s.z; m.c[2] = txz - s.y;
+        m.c[3] = txy - s.z; m.c[4] = a.y * axis.y + cosAngle; m.c[5] = tyz + s.x;
+        m.c[6] = txz + s.y; m.c[7] = tyz - s.x; m.c[8] = a.z * axis.z + cosAngle;
+        Transform(m);
+    }
+    void Translate(V3 p) { pos = pos + p; } // scene.h:229
+    void Store(bhrt_xform &o) const
+    {
+        memcpy(o.tm, tm.c, sizeof o.tm);
+        memcpy(o.itm, itm.c, sizeof o.itm);
+        o.pos[0] = pos.x; o.pos[1] = pos.y; o.pos[2] = pos.z;
+    }
+};
+
+struct Col {
+    float r, g, b;
+};
+
+bool NameIs(const XmlElement *e, const char *s) { return strcasecmp(e->name.c_str(), s) == 0; } // xmlload.cpp:34-38
+
+void ReadFloat(const XmlElement *e, float &f, const char *name = "value") // xmlload.cpp:516-521
+{
+    double d = (double)f;
+    e->QueryDouble(name, &d);
+    f = (float)d;
+}
+void ReadVector(const XmlElement *e, V3 &v) // xmlload.cpp:478-493
+{
+    double x = (double)v.x, y = (double)v.y, z = (double)v.z;
+    e->QueryDouble("x", &x); e->QueryDouble("y", &y); e->QueryDouble("z", &z);
+    v.x = (float)x; v.y = (float)y; v.z = (float)z;
+    float f = 1;
+    ReadFloat(e, f);
+    v = v * f;
+}
+void ReadColor(const XmlElement *e, Col &c) // xmlload.cpp:497-512
+{
+    double r = (double)c.r, g = (double)c.g, b = (double)c.b;
+    e->QueryDouble("r", &r); e->QueryDouble("g", &g); e->QueryDouble("b", &b);
+    c.r = (float)r; c.g = (float)g; c.b = (float)b;
+    float f = 1;
+    ReadFloat(e, f);
+    c.r *= f; c.g *= f; c.b *= f;
+}
+void LoadTransform(Xform &t, const XmlElement *e) // xmlload.cpp:275-303
+{
+    for (auto &ch : e->children) {
+        const XmlElement *c = ch.get();
+        if (NameIs(c, "scale")) {
+            V3 s = {1, 1, 1};
+            ReadVector(c, s);
+            t.Scale(s.x, s.y, s.z);
+        } else if (NameIs(c, "rotate")) {
+            V3 s = {0, 0, 0};
+            ReadVector(c, s);
+            s = normalized(s);
+            float a = 0; // the reference leaves `a` uninitialised when angle= is absent
+            ReadFloat(c, a, "angle");
+            t.Rotate(s, a);
+        } else if (NameIs(c, "translate")) {
+            V3 p = {0, 0, 0};
+            ReadVector(c, p);
+            t.Translate(p);
+        }
+    }
+}
+
+std::string NormalisePath(const char *p) // Windows separators in 9 of 19 shipped scenes
+{
+    std::string s = p ? p : "";
+    for (auto &ch : s) if (ch == '\\') ch = '/';
+    return s;
+}
+
+struct TexData {
+    int type = BHRT_TEX_FILE;
+    int w = 0, h = 0;
+    Col c1 = {0, 0, 0}, c2 = {1, 1, 1};
+    std::vector<uint8_t> rgb;
+};
+struct TexMapData {
+    Xform xf;
+    int texture = -1;
+};
+struct TexColorData {
+    Col color = {0, 0, 0};
+    int map = -1;
+};
+struct MaterialData {
+    std::string name;
+    int kind = BHRT_MTL_BLINN;
+    TexColorData diffuse, specular, refraction;
+    float glossiness = 20.0f;
+    Col absorption = {0, 0, 0};
+    float ior = 1;
+    float refraction_glossiness = 0;
+    MaterialData() // materials.h:23-25
+    {
+        diffuse.color = {0.5f, 0.5f, 0.5f};
+        specular.color = {0.7f, 0.7f, 0.7f};
+        refraction.color = {0, 0, 0};
+    }
+};
+struct LightData {
+    int type;
+    Col intensity = {0, 0, 0};
+    V3 vec = {0, 0, 0};
+    float size = 0;
+    float Gray() const { return (intensity.r + intensity.g + intensity.b) / 3.0f; } // cyColor.h Gray()
+};
+struct NodeData {
+    Xform xf;
+    int parent = -1, depth = 1, obj_type = BHRT_OBJ_NONE, mesh = -1, material = -1;
+    int subtree_end = 0;
+    std::string material_name;
+    bool has_material_name = false;
+};
+
+struct Loader {
+    std::string xml_dir;
+    FlatScene *out;
+    std::vector<NodeData> nodes;
+    std::vector<std::pair<int, std::string>> node_mtl_list; // xmlload.cpp:55-61
+    std::vector<MaterialData> materials;
+    std::vector<LightData> lights;
+    std::vector<std::unique_ptr<HostMesh>> meshes;
+    std::map<std::string, int> mesh_by_name; // objList.Find (scene.h:187)
+    std::vector<TexData> textures;
+    std::map<std::string, int> tex_by_name; // textureList.Find
+    std::vector<TexMapData> texmaps;
+    TexColorData background, environment;
+
+    void Warn(const std::string &w) { out->warnings.push_back(w); }
+
+    // The reference opens asset paths relative to the process cwd.  Same here; additionally the
+    // scene file's own directory and $BHRT_ASSET_ROOT are tried so scenes are relocatable.
+    std::string Resolve(const std::string &name)
+    {
+        std::string n = NormalisePath(name.c_str());
+        std::vector<std::string> cands = {n};
+        if (!xml_dir.empty()) cands.push_back(xml_dir + "/" + n);
+        if (const char *root = getenv("BHRT_ASSET_ROOT")) cands.push_back(std::string(root) + "/" + n);
+        for (auto &c : cands) {
+            FILE *fp = fopen(c.c_str(), "rb");
+            if (fp) { fclose(fp); return c; }
+        }
+        return n;
+    }
+
+    int FindMaterial(const std::string &name) // scene.h:305: first match
+    {
+        for (size_t i = 0; i < materials.size(); i++)
+            if (materials[i].name == name) return (int)i;
+        return -1;
+    }
+
+    int ReadTextureFile(const char *texName) // xmlload.cpp:562-582 + Texture.cpp:58-93
+    {
+        auto it = tex_by_name.find(texName);
+        if (it != tex_by_name.end()) return it->second;
+        std::string path = Resolve(texName);
+        TexData t;
+        t.type = BHRT_TEX_FILE;
+        bool ok = false;
+        size_t len = path.size();
+        if (len >= 3) {
+            char ext[4] = {(char)tolower(path[len - 3]), (char)tolower(path[len - 2]), (char)tolower(path[len - 1]), 0};
+            if (!strcmp(ext, "png")) ok = LoadPngRgb(path.c_str(), t.rgb, t.w, t.h);
+            else if (!strcmp(ext, "ppm")) ok = LoadPpm(path.c_str(), t);
+        }
+        if (!ok) {
+            Warn(std::string("texture: error loading file \"") + texName + "\"");
+            return -1; // not cached: the reference retries (and fails) every time
+        }
+        textures.push_back(std::move(t));
+        tex_by_name[texName] = (int)textures.size() - 1;
+        return (int)textures.size() - 1;
+    }
+    static bool LoadPpm(const char *path, TexData &t) // Texture.cpp:32-54 (binary P6, maxval line skipped)
+    {
+        FILE *fp = fopen(path, "rb");
+        if (!fp) return false;
+        auto readLine = [&](char *buf, int size) {
+            int i;
+            for (i = 0; i < size; i++) {
+                int c = fgetc(fp);
+                buf[i] = (char)c;
+                if (feof(fp) || buf[i] == '\n' || buf[i] == '\r') { buf[i] = 0; return; }
+            }
+            buf[size - 1] = 0;
+        };
+        char buf[1024];
+        readLine(buf, 1024);
+        if (buf[0] != 'P' && buf[1] != '6') { fclose(fp); return false; }
+        readLine(buf, 1024);
+        while (buf[0] == '#') readLine(buf, 1024);
+        if (sscanf(buf, "%d %d", &t.w, &t.h) != 2 || t.w <= 0 || t.h <= 0) { fclose(fp); return false; }
+        readLine(buf, 1024);
+        while (buf[0] == '#') readLine(buf, 1024);
+        t.rgb.resize((size_t)t.w * t.h * 3);
+        size_t got = fread(t.rgb.data(), 3, (size_t)t.w * t.h, fp);
+        (void)got;
+        fclose(fp);
+        return true;
+    }
+
+    int ReadTexture(const XmlElement *e) // xmlload.cpp:525-558; returns texmap index or -1
+    {
+        const char *texName = e->Attribute("texture");
+        if (!texName) return -1;
+        int tex = -1;
+        if (strcasecmp(texName, "checkerboard") == 0) {
+            TexData t;
+            t.type = BHRT_TEX_CHECKER;
+            for (auto &ch : e->children) {
+                if (NameIs(ch.get(), "color1")) { Col c = {0, 0, 0}; ReadColor(ch.get(), c); t.c1 = c; }
+                else if (NameIs(ch.get(), "color2")) { Col c = {0, 0, 0}; ReadColor(ch.get(), c); t.c2 = c; }
+            }
+            textures.push_back(std::move(t));
+            tex = (int)textures.size() - 1;
+        } else {
+            tex = ReadTextureFile(texName);
+        }
+        TexMapData m;
+        m.texture = tex;
+        LoadTransform(m.xf, e);
+        texmaps.push_back(m);
+        return (int)texmaps.size() - 1;
+    }
+
+    void LoadMaterial(const XmlElement *e) // xmlload.cpp:307-390
+    {
+        const char *name = e->Attribute("name");
+        const char *type = e->Attribute("type");
+        if (!type || strcasecmp(type, "blinn") != 0) return; // unknown type: not appended
+        MaterialData m;
+        m.name = name ? name : "";
+        for (auto &chp : e->children) {
+            const XmlElement *c = chp.get();
+            Col col = {1, 1, 1};
+            float f = 1;
+            if (NameIs(c, "diffuse")) { ReadColor(c, col); m.diffuse.color = col; m.diffuse.map = ReadTexture(c); }
+            else if (NameIs(c, "specular")) { ReadColor(c, col); m.specular.color = col; m.specular.map = ReadTexture(c); }
+            else if (NameIs(c, "glossiness")) { ReadFloat(c, f); m.glossiness = f; }
+            else if (NameIs(c, "emission")) { ReadTexture(c); /* parsed, never shaded */ }
+            else if (NameIs(c, "reflection")) { ReadTexture(c); /* parsed, never shaded (Q8) */ }
+            else if (NameIs(c, "refraction")) {
+                ReadColor(c, col);
+                m.refraction.color = col;
+                ReadFloat(c, f, "index");
+                m.ior = f;
+                m.refraction.map = ReadTexture(c);
+                f = 0;
+                ReadFloat(c, f, "glossiness");
+                m.refraction_glossiness = f;
+            } else if (NameIs(c, "absorption")) { ReadColor(c, col); m.absorption = col; }
+        }
+        materials.push_back(m);
+    }
+
+    void LoadLight(const XmlElement *e) // xmlload.cpp:394-474
+    {
+        const char *type = e->Attribute("type");
+        if (!type) return;
+        LightData l;
+        if (strcasecmp(type, "ambient") == 0) {
+            l.type = BHRT_LIGHT_AMBIENT;
+            for (auto &c : e->children)
+                if (NameIs(c.get(), "intensity")) { Col col = {1, 1, 1}; ReadColor(c.get(), col); l.intensity = col; }
+        } else if (strcasecmp(type, "direct") == 0) {
+            l.type = BHRT_LIGHT_DIRECT;
+            l.vec = {0, 0, 1}; // lights.h:48
+            for (auto &c : e->children) {
+                if (NameIs(c.get(), "intensity")) { Col col = {1, 1, 1}; ReadColor(c.get(), col); l.intensity = col; }
+                else if (NameIs(c.get(), "direction")) { V3 v = {1, 1, 1}; ReadVector(c.get(), v); l.vec = normalized(v); }
+            }
+        } else if (strcasecmp(type, "point") == 0) {
+            l.type = BHRT_LIGHT_POINT;
+            for (auto &c : e->children) {
+                if (NameIs(c.get(), "intensity")) { Col col = {1, 1, 1}; ReadColor(c.get(), col); l.intensity = col; }
+                else if (NameIs(c.get(), "position")) { V3 v = {0, 0, 0}; ReadVector(c.get(), v); l.vec = v; }
+                else if (NameIs(c.get(), "size")) { float f = 0; ReadFloat(c.get(), f); l.size = f; }
+            }
+        } else
+            return;
+        lights.push_back(l);
+    }
+
+    // MultiMtl built from a mesh's .mtl (xmlload.cpp:219-250).  Shade() dispatches on hInfo.mtlID,
+    // which triangle hits never set -> sub-material 0 is the only one ever shaded.
+    void AppendMultiMtl(const std::string &name, const HostMesh &mesh)
+    {
+        MaterialData m;
+        m.name = name;
+        if (mesh.mtls.empty()) { m.kind = BHRT_MTL_WHITE; materials.push_back(m); return; }
+        const HostMesh::Mtl &s = mesh.mtls[0];
+        m.diffuse.color = {s.Kd[0], s.Kd[1], s.Kd[2]};
+        m.specular.color = {s.Ks[0], s.Ks[1], s.Ks[2]};
+        m.glossiness = s.Ns;
+        m.ior = s.Ni;
+        // every mesh material's textures are loaded by the reference (side effect: texture list); sub-material 0's are used
+        for (size_t i = 0; i < mesh.mtls.size(); i++) {
+            const HostMesh::Mtl &mi = mesh.mtls[i];
+            int mapKd = -1, mapKs = -1;
+            if (!mi.map_Kd.empty()) { TexMapData t; t.texture = ReadTextureFile(mi.map_Kd.c_str()); texmaps.push_back(t); mapKd = (int)texmaps.size() - 1; }
+            if (!mi.map_Ks.empty()) { TexMapData t; t.texture = ReadTextureFile(mi.map_Ks.c_str()); texmaps.push_back(t); mapKs = (int)texmaps.size() - 1; }
+            if (i == 0) {
+                if (mapKd >= 0) m.diffuse.map = mapKd;
+                if (mapKs >= 0) m.diffuse.map = mapKs; // xmlload.cpp:230 sets the DIFFUSE texture from map_Ks (sic)
+            }
+        }
+        if (s.illum > 2 && s.illum <= 7) {
+            float gloss = acosf(powf(2, 1 / s.Ns));
+            if (s.illum >= 6) {
+                m.refraction.color = {1 - s.Tf[0], 1 - s.Tf[1], 1 - s.Tf[2]};
+                m.refraction_glossiness = gloss;
+            }
+        }
+        materials.push_back(m);
+    }
+
+    void LoadNode(int parent, int depth, const XmlElement *e) // xmlload.cpp:172-271
+    {
+        int idx = (int)nodes.size();
+        nodes.emplace_back();
+        nodes[idx].parent = parent;
+        nodes[idx].depth = depth;
+        const char *name = e->Attribute("name");
+        const char *mtlName = e->Attribute("material");
+        if (mtlName) node_mtl_list.emplace_back(idx, mtlName);
+        const char *type = e->Attribute("type");
+        if (type) {
+            if (strcasecmp(type, "sphere") == 0) nodes[idx].obj_type = BHRT_OBJ_SPHERE;
+            else if (strcasecmp(type, "plane") == 0) nodes[idx].obj_type = BHRT_OBJ_PLANE;
+            else if (strcasecmp(type, "obj") == 0) {
+                std::string key = name ? name : "";
+                auto it = mesh_by_name.find(key);
+                int mi = -1;
+                if (it != mesh_by_name.end()) mi = it->second;
+                else {
+                    std::unique_ptr<HostMesh> hm(new HostMesh);
+                    std::string err;
+                    std::string path = Resolve(key);
+                    if (!name || !LoadObj(path.c_str(), mtlName == nullptr, *hm, err)) {
+                        Warn("ERROR: Cannot load file \"" + key + "\" (" + err + "); node keeps a null object");
+                    } else {
+                        if (hm->vn.empty()) ComputeNormals(*hm);
+                        ComputeBoundingBox(*hm);
+                        if (!hm->had_vt) Warn("mesh \"" + key + "\" has no vt lines: the reference dereferences null here (SURVEY.md Q12); uvw = 0 is used");
+                        BuildBvh(*hm, 4);
+                        meshes.push_back(std::move(hm));
+                        mi = (int)meshes.size() - 1;
+                        mesh_by_name[key] = mi;
+                        if (!meshes[mi]->mtls.empty() && FindMaterial(key) < 0) { // xmlload.cpp:219-250
+                            AppendMultiMtl(key, *meshes[mi]);
+                            node_mtl_list.emplace_back(idx, key);
+                        }
+                    }
+                }
+                if (mi >= 0) { nodes[idx].obj_type = BHRT_OBJ_MESH; nodes[idx].mesh = mi; }
+            } else
+                Warn(std::string("object: unknown type \"") + type + "\"");
+        }
+        for (auto &c : e->children)
+            if (NameIs(c.get(), "object")) LoadNode(idx, depth + 1, c.get());
+        nodes[idx].subtree_end = (int)nodes.size();
+        LoadTransform(nodes[idx].xf, e);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// blob writer
+// ------------------------------------------------------------------------------------------------
+struct BlobWriter {
+    std::vector<uint8_t> &b;
+    explicit BlobWriter(std::vector<uint8_t> &v) : b(v) {}
+    uint64_t Append(const void *p, size_t n)
+    {
+        while (b.size() % 16) b.push_back(0);
+        uint64_t off = b.size();
+        if (n) b.insert(b.end(), (const uint8_t *)p, (const uint8_t *)p + n);
+        return off;
+    }
+};
+
+void StoreTexColor(bhrt_texcolor &o, const TexColorData &t)
+{
+    o.color[0] = t.color.r; o.color[1] = t.color.g; o.color[2] = t.color.b;
+    o.map = t.map;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// OBJ / MTL  (cyTriMesh.h:263-547)
+// ------------------------------------------------------------------------------------------------
+namespace {
+// One logical line: leading blanks and '#' comment lines skipped, inner runs of blanks collapsed to a
+// single space, cut at 1023 characters (Buffer::ReadLine, cyTriMesh.h:278-305).
+struct LineReader {
+    const std::string &s;
+    size_t p = 0;
+    bool eof = false;
+    explicit LineReader(const std::string &text) : s(text) {}
+    int Get()
+    {
+        if (p < s.size()) return (unsigned char)s[p++];
+        eof = true;
+        return -1;
+    }
+    int Read(std::string &line)
+    {
+        line.clear();
+        int c = Get();
+        while (!eof) {
+            while (c >= 0 && isspace(c)) c = Get();
+            if (c == '#') { while (!eof && c != '\n' && c != '\r' && c != 0) c = Get(); }
+            else break;
+        }
+        bool inspace = false;
+        while (line.size() < 1023) {
+            if (eof || c == '\n' || c == '\r' || c == 0) break;
+            if (isspace(c)) inspace = true;
+            else {
+                if (inspace) line.push_back(' ');
+                inspace = false;
+                line.push_back((char)c);
+            }
+            c = Get();
+        }
+        return (int)line.size();
+    }
+};
+bool IsCommand(const std::string &l, const char *cmd)
+{
+    size_t n = strlen(cmd);
+    if (l.compare(0, n, cmd) != 0) return false;
+    return l.size() == n || l[n] == ' ';
+}
+void ReadVertex(const std::string &l, float *v)
+{
+    v[0] = v[1] = v[2] = 0;
+    if (l.size() > 2) sscanf(l.c_str() + 2, "%f %f %f", &v[0], &v[1], &v[2]);
+}
+void ReadFloat3(const std::string &l, float *f)
+{
+    f[0] = f[1] = f[2] = 0;
+    int n = l.size() > 2 ? sscanf(l.c_str() + 2, "%f %f %f", &f[0], &f[1], &f[2]) : 0;
+    if (n == 1) f[2] = f[1] = f[0];
+}
+std::string CopyFrom(const std::string &l, size_t start)
+{
+    while (start < l.size() && l[start] <= ' ') start++;
+    return start < l.size() ? l.substr(start) : std::string();
+}
+bool ReadWholeFile(const char *path, std::string &text)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return false;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, n);
+    fclose(fp);
+    return true;
+}
+} // namespace
+
+bool LoadObj(const char *path, bool load_mtl, HostMesh &m, std::string &err)
+{
+    std::string text;
+    if (!ReadWholeFile(path, text)) { err = "cannot open file"; return false; }
+    struct MtlData { std::string name; unsigned firstFace = 0, faceCount = 0; };
+    std::vector<MtlData> mtlData;
+    std::vector<std::string> mtlFiles;
+    std::vector<int> faceMtlIndex;
+    std::vector<float> _v, _vn, _vt;
+    std::vector<uint32_t> _f, _fn, _ft;
+    int currentMtl = -1;
+    bool hasTextures = false, hasNormals = false;
+
+    LineReader rd(text);
+    std::string line;
+    while (int rb = rd.Read(line)) {
+        if (IsCommand(line, "v")) { float v[3]; ReadVertex(line, v); _v.insert(_v.end(), v, v + 3); }
+        else if (IsCommand(line, "vt")) { float v[3]; ReadVertex(line, v); _vt.insert(_vt.end(), v, v + 3); hasTextures = true; }
+        else if (IsCommand(line, "vn")) { float v[3]; ReadVertex(line, v); _vn.insert(_vn.end(), v, v + 3); hasNormals = true; }
+        else if (IsCommand(line, "f")) {
+            // fan triangulation + 1-based / negative indices (cyTriMesh.h:379-438)
+            int facevert = -1;
+            bool inspace = true, negative = false;
+            int type = 0;
+            unsigned index = 0;
+            uint32_t face[3] = {0, 0, 0}, tface[3] = {0, 0, 0}, nface[3] = {0, 0, 0};
+            size_t nFacesBefore = _f.size() / 3;
+            auto push = [&]() {
+                _f.insert(_f.end(), face, face + 3);
+                if (hasTextures) _ft.insert(_ft.end(), tface, tface + 3);
+                if (hasNormals) _fn.insert(_fn.end(), nface, nface + 3);
+                faceMtlIndex.push_back(currentMtl);
+            };
+            for (int i = 2; i < rb; i++) {
+                char ch = line[i];
+                if (ch == ' ') { inspace = true; continue; }
+                if (inspace) {
+                    inspace = false; negative = false; type = 0; index = 0;
+                    if (facevert < 2) {
+                        if (facevert == -1) { face[0] = face[1] = face[2] = 0; tface[0] = tface[1] = tface[2] = 0; nface[0] = nface[1] = nface[2] = 0; }
+                        facevert++;
+                    } else {
+                        push();
+                        face[1] = face[2];
+                        if (hasTextures) tface[1] = tface[2];
+                        if (hasNormals) nface[1] = nface[2];
+                    }
+                }
+                if (ch == '/') { type++; index = 0; }
+                if (ch == '-') negative = true;
+                if (ch >= '0' && ch <= '9') {
+                    index = index * 10 + (unsigned)(ch - '0');
+                    switch (type) {
+                    case 0: face[facevert] = negative ? (unsigned)(_v.size() / 3) - index : index - 1; break;
+                    case 1: tface[facevert] = negative ? (unsigned)(_vt.size() / 3) - index : index - 1; hasTextures = true; break;
+                    case 2: nface[facevert] = negative ? (unsigned)(_vn.size() / 3) - index : index - 1; hasNormals = true; break;
+                    }
+                }
+            }
+            push();
+            if (currentMtl >= 0) mtlData[currentMtl].faceCount += (unsigned)(_f.size() / 3 - nFacesBefore);
+        } else if (load_mtl) {
+            if (IsCommand(line, "usemtl")) {
+                std::string nm = line.size() > 7 ? line.substr(7) : std::string();
+                if (nm.empty()) currentMtl = 0;
+                else {
+                    int found = -1;
+                    for (size_t i = 0; i < mtlData.size(); i++) if (mtlData[i].name == nm) { found = (int)i; break; }
+                    if (found < 0) { MtlData d; d.name = nm; d.firstFace = (unsigned)(_f.size() / 3); mtlData.push_back(d); found = (int)mtlData.size() - 1; }
+                    currentMtl = found;
+                }
+            }
+            if (IsCommand(line, "mtllib")) mtlFiles.push_back(line.size() > 7 ? line.substr(7) : std::string());
+        }
+        if (rd.eof) break;
+    }
+    const size_t nf = _f.size() / 3;
+    if (nf == 0) { err = "no faces"; return false; } // the reference would go on to crash on an empty BVH
+    if ((!_ft.empty() && _ft.size() != _f.size()) || (!_fn.empty() && _fn.size() != _f.size())) {
+        err = "faces mix vertex formats (v, v/vt, v//vn) in a way the reference mis-handles";
+        return false;
+    }
+    for (size_t i = 0; i < _f.size(); i++)
+        if (_f[i] >= _v.size() / 3) { err = "face vertex index out of range"; return false; }
+    for (size_t i = 0; i < _ft.size(); i++)
+        if (_ft[i] >= _vt.size() / 3) { err = "face texture index out of range"; return false; }
+    for (size_t i = 0; i < _fn.size(); i++)
+        if (!_vn.empty() && _fn[i] >= _vn.size() / 3) { err = "face normal index out of range"; return false; }
+
+    m.v = _v; m.vt = _vt; m.vn = _vn;
+    m.f.assign(_f.size(), 0);
+    m.ft.assign(_vt.empty() ? 0 : _f.size(), 0);
+    m.fn.assign(_vn.empty() ? 0 : _f.size(), 0);
+    bool useFt = !m.ft.empty() && !_ft.empty(), useFn = !m.fn.empty() && !_fn.empty();
+    auto copyFace = [&](size_t dst, size_t src) {
+        for (int k = 0; k < 3; k++) {
+            m.f[dst * 3 + k] = _f[src * 3 + k];
+            if (useFt) m.ft[dst * 3 + k] = _ft[src * 3 + k];
+            if (useFn) m.fn[dst * 3 + k] = _fn[src * 3 + k];
+        }
+    };
+    if (load_mtl) { m.mtls.resize(mtlData.size()); m.mcfc.assign(mtlData.size(), 0); }
+    if (!mtlData.empty()) { // faces regrouped by material (cyTriMesh.h:461-487)
+        size_t fid = 0;
+        for (size_t mi = 0; mi < mtlData.size(); mi++) {
+            for (size_t i = mtlData[mi].firstFace, j = 0; j < mtlData[mi].faceCount && i < nf; i++)
+                if (faceMtlIndex[i] == (int)mi) { copyFace(fid++, i); j++; }
+            m.mcfc[mi] = (int)fid;
+        }
+        if (fid < nf)
+            for (size_t i = 0; i < nf; i++)
+                if (faceMtlIndex[i] < 0) copyFace(fid++, i);
+    } else
+        for (size_t i = 0; i < nf; i++) copyFace(i, i);
+
+    if (load_mtl) { // .mtl files (cyTriMesh.h:498-544)
+        std::string p = path, dir;
+        size_t slash = p.find_last_of("/\\");
+        if (slash != std::string::npos) dir = p.substr(0, slash + 1);
+        for (auto &lib : mtlFiles) {
+            std::string mt;
+            if (!ReadWholeFile((dir + lib).c_str(), mt)) continue;
+            LineReader mr(mt);
+            int id = -1;
+            while (mr.Read(line)) {
+                if (IsCommand(line, "newmtl")) {
+                    std::string nm = line.size() > 7 ? line.substr(7) : std::string();
+                    id = -1;
+                    for (size_t i = 0; i < mtlData.size(); i++) if (mtlData[i].name == nm) { id = (int)i; break; }
+                    if (id >= 0) m.mtls[id].name = CopyFrom(line, 7);
+                } else if (id >= 0) {
+                    HostMesh::Mtl &M = m.mtls[id];
+                    if (IsCommand(line, "Ka")) ReadFloat3(line, M.Ka);
+                    else if (IsCommand(line, "Kd")) ReadFloat3(line, M.Kd);
+                    else if (IsCommand(line, "Ks")) ReadFloat3(line, M.Ks);
+                    else if (IsCommand(line, "Tf")) ReadFloat3(line, M.Tf);
+                    else if (IsCommand(line, "Ns")) sscanf(line.c_str() + 2, "%f", &M.Ns);
+                    else if (IsCommand(line, "Ni")) sscanf(line.c_str() + 2, "%f", &M.Ni);
+                    else if (IsCommand(line, "illum")) sscanf(line.c_str() + 5, "%d", &M.illum);
+                    else if (IsCommand(line, "map_Kd")) M.map_Kd = CopyFrom(line, 7);
+                    else if (IsCommand(line, "map_Ks")) M.map_Ks = CopyFrom(line, 7);
+                }
+                if (mr.eof) break;
+            }
+        }
+    }
+    m.had_vt = !m.vt.empty();
+    if (!m.had_vt) { // the reference crashes; define uvw = 0
+        m.vt = {0, 0, 0};
+        m.ft.assign(m.f.size(), 0);
+    }
+    return true;
+}
+
+void ComputeNormals(HostMesh &m) // cyTriMesh.h:248-261 (area-weighted, counter-clockwise)
+{
+    size_t nv = m.v.size() / 3, nf = m.f.size() / 3;
+    std::vector<V3> vn(nv, v3(0, 0, 0));
+    auto V = [&](uint32_t i) { return v3(m.v[i * 3], m.v[i * 3 + 1], m.v[i * 3 + 2]); };
+    m.fn.assign(m.f.size(), 0);
+    for (size_t i = 0; i < nf; i++) {
+        uint32_t a = m.f[i * 3], b = m.f[i * 3 + 1], c = m.f[i * 3 + 2];
+        V3 N = cross(V(b) - V(a), V(c) - V(a));
+        vn[a] = vn[a] + N; vn[b] = vn[b] + N; vn[c] = vn[c] + N; // same vertex twice in a face accumulates twice, like +=
+        for (int k = 0; k < 3; k++) m.fn[i * 3 + k] = m.f[i * 3 + k];
+    }
+    m.vn.resize(nv * 3);
+    for (size_t i = 0; i < nv; i++) {
+        V3 n = normalized(vn[i]);
+        m.vn[i * 3] = n.x; m.vn[i * 3 + 1] = n.y; m.vn[i * 3 + 2] = n.z;
+    }
+}
+
+void ComputeBoundingBox(HostMesh &m) // cyTriMesh.h:229-246
+{
+    size_t nv = m.v.size() / 3;
+    if (!nv) return;
+    for (int k = 0; k < 3; k++) m.bound_min[k] = m.bound_max[k] = m.v[k];
+    for (size_t i = 1; i < nv; i++)
+        for (int k = 0; k < 3; k++) {
+            float x = m.v[i * 3 + k];
+            if (m.bound_min[k] > x) m.bound_min[k] = x;
+            if (m.bound_max[k] < x) m.bound_max[k] = x;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BVH build (cyBVH.h:122-142, 242-328, 356-375)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Bx {
+    float b[6];
+    Bx() { b[0] = b[1] = b[2] = 1e30f; b[3] = b[4] = b[5] = -1e30f; }
+    void Add(const Bx &o)
+    {
+        for (int i = 0; i < 3; i++) {
+            if (b[i] > o.b[i]) b[i] = o.b[i];
+            if (b[i + 3] < o.b[i + 3]) b[i + 3] = o.b[i + 3];
+        }
+    }
+};
+struct TempNode {
+    int child1 = -1, child2 = -1;
+    Bx box;
+    unsigned count = 0, offset = 0;
+};
+struct BvhBuilder {
+    const HostMesh &m;
+    std::vector<uint32_t> elems;
+    std::vector<TempNode> t;
+    unsigned maxPer;
+    BvhBuilder(const HostMesh &mesh, unsigned mp) : m(mesh), maxPer(mp) {}
+    Bx ElemBounds(unsigned i) const
+    {
+        Bx x;
+        const float *p = &m.v[m.f[i * 3] * 3];
+        x.b[0] = x.b[3] = p[0]; x.b[1] = x.b[4] = p[1]; x.b[2] = x.b[5] = p[2];
+        for (int j = 1; j < 3; j++) {
+            const float *q = &m.v[m.f[i * 3 + j] * 3];
+            for (int k = 0; k < 3; k++) {
+                if (x.b[k] > q[k]) x.b[k] = q[k];
+                if (x.b[k + 3] < q[k]) x.b[k + 3] = q[k];
+            }
+        }
+        return x;
+    }
+    float ElemCenter(unsigned i, int dim) const // cyBVH.h:371-375
+    {
+        return (m.v[m.f[i * 3] * 3 + dim] + m.v[m.f[i * 3 + 1] * 3 + dim] + m.v[m.f[i * 3 + 2] * 3 + dim]) / 3.0f;
+    }
+    unsigned MeanSplit(unsigned n, uint32_t *e, const float *box) // cyBVH.h:295-328
+    {
+        if (n <= maxPer) return 0;
+        float d[3] = {box[3] - box[0], box[4] - box[1], box[5] - box[2]};
+        unsigned sd[3];
+        sd[0] = d[0] >= d[1] ? (d[0] >= d[2] ? 0 : 2) : (d[1] >= d[2] ? 1 : 2);
+        sd[1] = (sd[0] + 1) % 3;
+        sd[2] = (sd[0] + 2) % 3;
+        if (d[sd[1]] < d[sd[2]]) std::swap(sd[1], sd[2]);
+        unsigned c1 = 0;
+        for (int s = 0; s < 3; s++) {
+            unsigned dim = sd[s];
+            float splitPos = 0.5f * (box[dim] + box[dim + 3]);
+            unsigned i = 0, j = n;
+            while (i < j) {
+                if (ElemCenter(e[i], dim) <= splitPos) i++;
+                else { j--; std::swap(e[i], e[j]); }
+            }
+            if (i < n && i > 0) { c1 = i; break; }
+        }
+        return c1;
+    }
+    void Split(int ti) // cyBVH.h:242-278
+    {
+        uint32_t *e = &elems[t[ti].offset];
+        unsigned n = t[ti].count;
+        unsigned c1 = MeanSplit(n, e, t[ti].box.b);
+        if (c1 == 0 || c1 >= n) {
+            if (n > 8) c1 = n / 2; // CY_BVH_MAX_ELEMENT_COUNT
+            else return;
+        }
+        Bx b1, b2;
+        for (unsigned i = 0; i < c1; i++) b1.Add(ElemBounds(e[i]));
+        for (unsigned i = c1; i < n; i++) b2.Add(ElemBounds(e[i]));
+        TempNode n1, n2;
+        n1.count = c1; n1.offset = t[ti].offset; n1.box = b1;
+        n2.count = n - c1; n2.offset = t[ti].offset + c1; n2.box = b2;
+        int i1 = (int)t.size();
+        t.push_back(n1);
+        int i2 = (int)t.size();
+        t.push_back(n2);
+        t[ti].child1 = i1; t[ti].child2 = i2;
+        Split(i1);
+        Split(i2);
+    }
+    unsigned NumNodes(int ti) const { return t[ti].child1 < 0 ? 1 : 1 + NumNodes(t[ti].child1) + NumNodes(t[ti].child2); }
+    unsigned Convert(std::vector<bhrt_bvh_node> &out, unsigned id, int ti, unsigned childIndex, unsigned parent, unsigned depth, unsigned &maxDepth)
+    { // cyBVH.h:281-291
+        bhrt_bvh_node &o = out[id];
+        memcpy(o.b, t[ti].box.b, sizeof o.b);
+        o.parent = parent;
+        if (depth > maxDepth) maxDepth = depth;
+        if (t[ti].child1 < 0) {
+            o.data = (t[ti].offset & ((1u << 28) - 1)) | ((t[ti].count - 1) << 28) | (1u << 31);
+            return childIndex;
+        }
+        o.data = childIndex & 0x7fffffffu;
+        unsigned next = Convert(out, childIndex, t[ti].child1, childIndex + 2, id, depth + 1, maxDepth);
+        return Convert(out, childIndex + 1, t[ti].child2, next, id, depth + 1, maxDepth);
+    }
+};
+} // namespace
+
+void BuildBvh(HostMesh &m, unsigned maxPer)
+{
+    unsigned nf = (unsigned)(m.f.size() / 3);
+    if (maxPer > 8) maxPer = 8;
+    BvhBuilder B(m, maxPer);
+    B.elems.resize(nf);
+    for (unsigned i = 0; i < nf; i++) B.elems[i] = i;
+    Bx box;
+    for (unsigned i = 0; i < nf; i++) box.Add(B.ElemBounds(i));
+    TempNode root;
+    root.count = nf; root.offset = 0; root.box = box;
+    B.t.reserve(2 * (size_t)nf + 2);
+    B.t.push_back(root);
+    B.Split(0);
+    unsigned n = B.NumNodes(0);
+    m.bvh.assign(n + 1, bhrt_bvh_node());
+    memset(m.bvh.data(), 0, sizeof(bhrt_bvh_node));
+    unsigned maxDepth = 0;
+    B.Convert(m.bvh, 1, 0, 2, 0, 0, maxDepth);
+    m.bvh_depth = maxDepth;
+    m.elems = B.elems;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LoadSceneXml
+// ------------------------------------------------------------------------------------------------
+int LoadSceneXml(const char *path, FlatScene &out, std::string &err)
+{
+    out.blob.clear();
+    out.warnings.clear();
+    XmlDocument doc;
+    if (!doc.LoadFile(path)) { err = std::string("Failed to load the file \"") + path + "\": " + doc.error; return 1; }
+    const XmlElement *xml = doc.FirstChild("xml");
+    if (!xml) { err = "No \"xml\" tag found."; return 2; }
+    const XmlElement *scene = xml->FirstChild("scene");
+    if (!scene) { err = "No \"scene\" tag found."; return 3; }
+    const XmlElement *cam = xml->FirstChild("camera");
+    if (!cam) { err = "No \"camera\" tag found."; return 4; }
+
+    Loader L;
+    L.out = &out;
+    {
+        std::string p = path;
+        size_t slash = p.find_last_of("/\\");
+        L.xml_dir = slash == std::string::npos ? std::string(".") : p.substr(0, slash);
+    }
+    for (auto &chp : scene->children) { // xmlload.cpp:140-168
+        const XmlElement *c = chp.get();
+        if (NameIs(c, "background")) { Col col = {1, 1, 1}; ReadColor(c, col); L.background.color = col; L.background.map = L.ReadTexture(c); }
+        else if (NameIs(c, "environment")) { Col col = {1, 1, 1}; ReadColor(c, col); L.environment.color = col; L.environment.map = L.ReadTexture(c); }
+        else if (NameIs(c, "object")) L.LoadNode(-1, 1, c);
+        else if (NameIs(c, "material")) L.LoadMaterial(c);
+        else if (NameIs(c, "light")) L.LoadLight(c);
+    }
+    for (auto &nm : L.node_mtl_list) { // xmlload.cpp:101-107
+        int mi = L.FindMaterial(nm.second);
+        if (mi >= 0) L.nodes[nm.first].material = mi;
+    }
+
+    bhrt_camera C;
+    memset(&C, 0, sizeof C);
+    { // xmlload.cpp:109-127 + scene.h:513-523
+        V3 pos = {0, 0, 0}, dir = {0, 0, -1}, up = {0, 1, 0};
+        float fov = 40, focaldist = 1, dof = 0;
+        int w = 200, h = 150;
+        dir = dir + pos;
+        for (auto &chp : cam->children) {
+            const XmlElement *c = chp.get();
+            if (NameIs(c, "position")) ReadVector(c, pos);
+            else if (NameIs(c, "target")) ReadVector(c, dir);
+            else if (NameIs(c, "up")) ReadVector(c, up);
+            else if (NameIs(c, "fov")) ReadFloat(c, fov);
+            else if (NameIs(c, "focaldist")) ReadFloat(c, focaldist);
+            else if (NameIs(c, "dof")) ReadFloat(c, dof);
+            else if (NameIs(c, "width")) c->QueryInt("value", &w);
+            else if (NameIs(c, "height")) c->QueryInt("value", &h);
+        }
+        dir = dir - pos;
+        dir = normalized(dir);
+        V3 x = cross(dir, up);
+        up = normalized(cross(x, dir));
+        if (w <= 0 || h <= 0) { err = "camera width/height must be positive"; return 5; }
+        C.pos[0] = pos.x; C.pos[1] = pos.y; C.pos[2] = pos.z;
+        C.dir[0] = dir.x; C.dir[1] = dir.y; C.dir[2] = dir.z;
+        C.up[0] = up.x; C.up[1] = up.y; C.up[2] = up.z;
+        C.fov = fov; C.focaldist = focaldist; C.dof = dof; C.width = w; C.height = h;
+        // BeginRender's camera frame, Main.cpp:179-192 (tan in double, PI = 3.14159265)
+        float aor = w / (float)h;
+        float tan_h_pov = (float)tan(fov / 2 * 3.14159265 / 180.0);
+        float l = focaldist;
+        float hh = 2 * l * tan_h_pov;
+        float ww = aor * hh;
+        V3 camZ = -dir, camY = up, camX = cross(camY, camZ);
+        V3 topLeft = pos - camZ * l + camY * hh / 2 - camX * ww / 2;
+        V3 ddx = camX * ww / (float)w; // int -> float promotion in Vec3 / T
+        V3 ddy = camY * hh / (float)h;
+        C.top_left[0] = topLeft.x; C.top_left[1] = topLeft.y; C.top_left[2] = topLeft.z;
+        C.dd_x[0] = ddx.x; C.dd_x[1] = ddx.y; C.dd_x[2] = ddx.z;
+        C.dd_y[0] = ddy.x; C.dd_y[1] = ddy.y; C.dd_y[2] = ddy.z;
+    }
+
+    // CalculateLightsIntensity (Main.cpp:116-123): std::sort ascending by Gray(), then a float sum
+    std::sort(L.lights.begin(), L.lights.end(), [](const LightData &a, const LightData &b) { return a.Gray() < b.Gray(); });
+    float allLight = 0;
+    for (auto &l : L.lights) allLight += l.Gray();
+
+    unsigned maxDepth = 0;
+    for (auto &n : L.nodes) if ((unsigned)n.depth > maxDepth) maxDepth = (unsigned)n.depth;
+    if (maxDepth > BHRT_MAX_NODE_DEPTH) { err = "scene graph deeper than BHRT_MAX_NODE_DEPTH"; return 6; }
+
+    // ---------------- flatten
+    std::vector<uint8_t> &blob = out.blob;
+    blob.assign(sizeof(bhrt_flat_header), 0);
+    BlobWriter W(blob);
+    bhrt_flat_header H;
+    memset(&H, 0, sizeof H);
+    H.magic = BHRT_FLAT_MAGIC; H.version = BHRT_FLAT_VERSION;
+    H.camera = C;
+    StoreTexColor(H.background, L.background);
+    StoreTexColor(H.environment, L.environment);
+    H.all_light_intensity = allLight;
+    H.max_node_depth = maxDepth;
+
+    std::vector<bhrt_node> nodes(L.nodes.size());
+    for (size_t i = 0; i < L.nodes.size(); i++) {
+        bhrt_node &o = nodes[i];
+        memset(&o, 0, sizeof o);
+        L.nodes[i].xf.Store(o.xf);
+        o.parent = L.nodes[i].parent; o.depth = L.nodes[i].depth; o.obj_type = L.nodes[i].obj_type;
+        o.mesh = L.nodes[i].mesh; o.material = L.nodes[i].material; o.subtree_end = L.nodes[i].subtree_end;
+    }
+    H.n_nodes = (uint32_t)nodes.size();
+    H.off_nodes = W.Append(nodes.data(), nodes.size() * sizeof(bhrt_node));
+
+    std::vector<bhrt_mesh> meshes(L.meshes.size());
+    for (size_t i = 0; i < L.meshes.size(); i++) {
+        const HostMesh &m = *L.meshes[i];
+        bhrt_mesh &o = meshes[i];
+        memset(&o, 0, sizeof o);
+        o.nv = (uint32_t)(m.v.size() / 3); o.nf = (uint32_t)(m.f.size() / 3);
+        o.nvn = (uint32_t)(m.vn.size() / 3); o.nvt = (uint32_t)(m.vt.size() / 3);
+        o.n_bvh_nodes = (uint32_t)m.bvh.size(); o.bvh_depth = m.bvh_depth;
+        o.off_v = W.Append(m.v.data(), m.v.size() * 4);
+        o.off_vn = W.Append(m.vn.data(), m.vn.size() * 4);
+        o.off_vt = W.Append(m.vt.data(), m.vt.size() * 4);
+        o.off_f = W.Append(m.f.data(), m.f.size() * 4);
+        o.off_fn = W.Append(m.fn.data(), m.fn.size() * 4);
+        o.off_ft = W.Append(m.ft.data(), m.ft.size() * 4);
+        o.off_bvh = W.Append(m.bvh.data(), m.bvh.size() * sizeof(bhrt_bvh_node));
+        o.off_elems = W.Append(m.elems.data(), m.elems.size() * 4);
+        std::vector<bhrt_tri> tris(o.nf);
+        for (uint32_t f = 0; f < o.nf; f++) {
+            memset(&tris[f], 0, sizeof(bhrt_tri));
+            memcpy(tris[f].v0, &m.v[m.f[f * 3] * 3], 12);
+            memcpy(tris[f].v1, &m.v[m.f[f * 3 + 1] * 3], 12);
+            memcpy(tris[f].v2, &m.v[m.f[f * 3 + 2] * 3], 12);
+        }
+        o.off_tris = W.Append(tris.data(), tris.size() * sizeof(bhrt_tri));
+        memcpy(o.bound_min, m.bound_min, 12);
+        memcpy(o.bound_max, m.bound_max, 12);
+    }
+    H.n_meshes = (uint32_t)meshes.size();
+
+    std::vector<bhrt_texture> textures(L.textures.size());
+    for (size_t i = 0; i < L.textures.size(); i++) {
+        bhrt_texture &o = textures[i];
+        memset(&o, 0, sizeof o);
+        const TexData &t = L.textures[i];
+        o.type = t.type; o.width = t.w; o.height = t.h;
+        o.color1[0] = t.c1.r; o.color1[1] = t.c1.g; o.color1[2] = t.c1.b;
+        o.color2[0] = t.c2.r; o.color2[1] = t.c2.g; o.color2[2] = t.c2.b;
+        o.off_data = W.Append(t.rgb.data(), t.rgb.size());
+    }
+    H.n_textures = (uint32_t)textures.size();
+    H.off_textures = W.Append(textures.data(), textures.size() * sizeof(bhrt_texture));
+
+    std::vector<bhrt_texmap> texmaps(L.texmaps.size());
+    for (size_t i = 0; i < L.texmaps.size(); i++) {
+        memset(&texmaps[i], 0, sizeof(bhrt_texmap));
+        L.texmaps[i].xf.Store(texmaps[i].xf);
+        texmaps[i].texture = L.texmaps[i].texture;
+    }
+    H.n_texmaps = (uint32_t)texmaps.size();
+    H.off_texmaps = W.Append(texmaps.data(), texmaps.size() * sizeof(bhrt_texmap));
+
+    std::vector<bhrt_material> mats(L.materials.size());
+    for (size_t i = 0; i < L.materials.size(); i++) {
+        bhrt_material &o = mats[i];
+        memset(&o, 0, sizeof o);
+        const MaterialData &m = L.materials[i];
+        o.kind = m.kind;
+        StoreTexColor(o.diffuse, m.diffuse); StoreTexColor(o.specular, m.specular); StoreTexColor(o.refraction, m.refraction);
+        o.glossiness = m.glossiness;
+        o.absorption[0] = m.absorption.r; o.absorption[1] = m.absorption.g; o.absorption[2] = m.absorption.b;
+        o.ior = m.ior; o.refraction_glossiness = m.refraction_glossiness;
+    }
+    H.n_materials = (uint32_t)mats.size();
+    H.off_materials = W.Append(mats.data(), mats.size() * sizeof(bhrt_material));
+
+    std::vector<bhrt_light> lights(L.lights.size());
+    for (size_t i = 0; i < L.lights.size(); i++) {
+        bhrt_light &o = lights[i];
+        memset(&o, 0, sizeof o);
+        o.type = L.lights[i].type;
+        o.intensity[0] = L.lights[i].intensity.r; o.intensity[1] = L.lights[i].intensity.g; o.intensity[2] = L.lights[i].intensity.b;
+        o.vec[0] = L.lights[i].vec.x; o.vec[1] = L.lights[i].vec.y; o.vec[2] = L.lights[i].vec.z;
+        o.size = L.lights[i].size;
+    }
+    H.n_lights = (uint32_t)lights.size();
+    H.off_lights = W.Append(lights.data(), lights.size() * sizeof(bhrt_light));
+    H.off_meshes = W.Append(meshes.data(), meshes.size() * sizeof(bhrt_mesh));
+    while (blob.size() % 16) blob.push_back(0);
+    H.total_bytes = blob.size();
+    memcpy(blob.data(), &H, sizeof H);
+    return 0;
+}
+
+} // namespace bhrt

@@ -1,0 +1,137 @@
+/* bhrt.h — C ABI of the MI355X-native render path (libbhrt.so).
+ *
+ * Drop-in boundary for the per-pixel render path of BosonHBC/BHRayTracer.  The reference has
+ * no FFI: its seam is three free functions plus `extern` globals shared between the UI and the
+ * renderer (all paths relative to /root/reference/BHRayTracer):
+ *     int  LoadScene(char const *filename);   Main.cpp:43, xmlload.cpp:65
+ *     void BeginRender();                     Main.cpp:178   (called from viewport.cpp:425-449)
+ *     void StopRender();                      Main.cpp:243
+ *     globals rootNode, camera, renderImage, lights, materials, ...   Main.cpp:17-37
+ * and, one level down, the plugin virtuals of Scenes/scene.h (Object::IntersectRay :256,
+ * Light::Illuminate :268, Material::Shade :291, Texture::Sample :314) reached through
+ * recursive() (Main.cpp:389) and GenLight::Shadow (Lights/GenLight.cpp:10).
+ * This header exports the same units with explicit ownership (an opaque scene handle instead of
+ * globals) and runtime options instead of the reference's compile-time #defines.
+ *
+ * Threading: calls on one bhrt_scene must not overlap; different scenes are independent.
+ * Errors: every function returns 0 on success, non-zero otherwise; bhrt_last_error() gives the
+ * message for the calling thread.  Compute entry points fail (never fall back to the CPU) when
+ * no gfx950 device is usable.
+ */
+#ifndef BHRT_H
+#define BHRT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bhrt_scene bhrt_scene;
+
+/* BHRT_HIT_* as in Scenes/scene.h:57-60 */
+#define BHRT_SIDE_FRONT 1
+#define BHRT_SIDE_BACK 2
+#define BHRT_SIDE_BOTH 3
+
+enum {
+    BHRT_OK = 0,
+    BHRT_ERR_IO = 1,
+    BHRT_ERR_PARSE = 2,
+    BHRT_ERR_ARG = 3,
+    BHRT_ERR_NO_DEVICE = 4,
+    BHRT_ERR_HIP = 5,
+    BHRT_ERR_UNSUPPORTED = 6,
+    BHRT_ERR_OVERFLOW = 7
+};
+
+typedef struct bhrt_info { /* replaces reading the globals camera / rootNode / lights (Main.cpp:17-30) */
+    int32_t width, height;
+    uint32_t n_nodes, n_meshes, n_triangles, n_bvh_nodes, n_materials, n_lights, n_textures;
+    uint32_t max_node_depth, max_bvh_depth;
+    uint64_t flat_bytes;
+    uint32_t n_warnings;
+} bhrt_info;
+
+/* Runtime form of the reference's compile-time knobs (SURVEY.md §5 "Config / flags"). */
+typedef struct bhrt_opts {
+    int32_t spp;              /* PT_SampleCount (Main.cpp:141), default 32 */
+    int32_t gi_bounces;       /* GIBounceCount (Main.cpp:130), default 3 */
+    int32_t internal_bounces; /* INTERNAL_REFLECTION_BOUNCE (Main.cpp:41), default 16 */
+    uint32_t seed;            /* stream seed of include/bhrt_rng.h (the reference never calls srand) */
+    int32_t jitter;           /* 1 = RandomPositionInPixel (Main.cpp:132-139); 0 = ray through the pixel corner */
+    int32_t gamma;            /* USE_GamaCorrection (Main.cpp:128): 1 = pow(c, 1/2.2f) before Color24 */
+    int32_t photon_map;       /* USE_PhotonMap (Main.cpp:51): 1 = gather from the caustic map built by bhrt_photon_build */
+    /* tile partition: this process renders tiles t with t % world_size == rank */
+    int32_t rank, world_size;
+    int32_t tile_size;        /* square tile edge in pixels, default 32 */
+    int32_t samples_per_pass; /* 0 = choose; upper bound on camera samples in flight per wavefront pass */
+    int32_t reserved[5];
+} bhrt_opts;
+
+typedef struct bhrt_stats {
+    uint64_t closest_rays;  /* top-level recursive() equivalents traced (Main.cpp:389) */
+    uint64_t shadow_rays;   /* GenLight::Shadow equivalents traced (GenLight.cpp:10) */
+    uint64_t shade_calls;   /* MtlBlinn::Shade equivalents evaluated */
+    uint64_t camera_samples;
+    uint32_t passes, wave_iterations;
+    double seconds_total;    /* wall clock of the call, scene already resident */
+    double seconds_trace_closest, seconds_trace_shadow, seconds_shade, seconds_other; /* HIP-event kernel time */
+    uint64_t launches_trace_closest, launches_trace_shadow;
+    double reserved[4];
+} bhrt_stats;
+
+/* compact hit record written by the trace kernel (SoA on the device: one array per field) */
+typedef struct bhrt_hits {
+    float *t;         /* HitInfo::z = ray parameter, BIGFLOAT on a miss */
+    int32_t *node;    /* flattened node index (DFS pre-order of the Node tree), -1 on a miss */
+    int32_t *prim;    /* triangle id for mesh hits, -1 otherwise */
+    int32_t *front;   /* HitInfo::front */
+} bhrt_hits;
+
+const char *bhrt_last_error(void);
+void bhrt_default_opts(bhrt_opts *opts);
+
+/* ---- scene (= LoadScene + the globals it fills) ------------------------------------------------ */
+int bhrt_scene_load_xml(const char *path, bhrt_scene **out);            /* xmlload.cpp:65 */
+void bhrt_scene_free(bhrt_scene *scene);
+int bhrt_scene_info(const bhrt_scene *scene, bhrt_info *info);
+int bhrt_scene_warning(const bhrt_scene *scene, uint32_t i, const char **text); /* the reference printf()s these */
+int bhrt_scene_flat(const bhrt_scene *scene, const void **blob, uint64_t *bytes); /* host copy of the HBM image (include/bhrt_flat.h) */
+
+/* ---- device residency ---------------------------------------------------------------------------- */
+int bhrt_scene_upload(bhrt_scene *scene, int device); /* copies the flat scene into HBM of `device`; idempotent */
+int bhrt_device_count(int *n);
+
+/* ---- the hot path --------------------------------------------------------------------------------- */
+/* recursive(&rootNode, ray, hit, bHit, hitSide) for n rays (Main.cpp:389-413).
+ * rays_soa: 6 arrays of n floats back to back (ox[n], oy[n], oz[n], dx[n], dy[n], dz[n]).
+ * *_host variants take host pointers (copies included); *_dev take device pointers + a hipStream_t. */
+int bhrt_trace_closest_host(bhrt_scene *scene, const float *rays_soa, int hit_side, size_t n, bhrt_hits out);
+int bhrt_trace_closest_dev(bhrt_scene *scene, const float *d_rays_soa, int hit_side, size_t n, bhrt_hits d_out, void *stream);
+/* GenLight::Shadow(ray, t_max) (Lights/GenLight.cpp:10-13): vis = 0 occluded / 1 visible */
+int bhrt_trace_shadow_host(bhrt_scene *scene, const float *rays_soa, const float *tmax, size_t n, float *vis);
+int bhrt_trace_shadow_dev(bhrt_scene *scene, const float *d_rays_soa, const float *d_tmax, size_t n, float *d_vis, void *stream);
+
+/* BeginRender() (Main.cpp:178-242) without the UI and without the PNG write: renders this rank's tiles.
+ * rgb8: W*H*3 bytes, row-major j*W+i like RenderImage::GetPixels (may be NULL);
+ * radiance: W*H*3 floats, the per-pixel average BEFORE gamma (may be NULL).
+ * Pixels of tiles owned by other ranks are left untouched.  Host pointers. */
+int bhrt_render(bhrt_scene *scene, const bhrt_opts *opts, uint8_t *rgb8, float *radiance, bhrt_stats *stats);
+/* same, but the outputs stay in HBM (device pointers; for timing and for the RCCL gather) */
+int bhrt_render_dev(bhrt_scene *scene, const bhrt_opts *opts, uint8_t *d_rgb8, float *d_radiance, bhrt_stats *stats, void *stream);
+/* per-sample radiance for a pixel region, keyed RNG (parity tests): out = region_pixels*spp*3 floats, host */
+int bhrt_render_samples(bhrt_scene *scene, const bhrt_opts *opts, int x0, int y0, int x1, int y1, float *samples, bhrt_stats *stats);
+
+/* ---- caustic photon map (Main.cpp:342-386, DataStructure/cyPhotonMap.h) -------------------------- */
+int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, uint32_t *n_stored);
+int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *n, size_t cnt, float radius, float *irrad, float *dir);
+int bhrt_photon_export(const bhrt_scene *scene, const char *dat_path); /* 24-byte records, Main.cpp:383-385 */
+
+/* ---- image output (RenderImage::SaveImage, Scenes/scene.h:628-644) ------------------------------- */
+int bhrt_save_png(const char *path, const uint8_t *rgb8, int width, int height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BHRT_H */

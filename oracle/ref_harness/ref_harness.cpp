@@ -1,0 +1,385 @@
+// ref_harness.cpp — drives the UNMODIFIED reference (compiled in place from
+// /root/reference, see oracle/Makefile) so that its own functions produce the golden
+// vectors this repo's oracle and HIP path are pinned against.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing here is shipped or linked into the product; the
+// binary is written to oracle/_ref/ (git-ignored) and exists only in the development
+// container (the reference cannot travel to the GPU box).
+//
+// How it reaches the reference: Main.cpp is included
+// textually with main renamed, which exposes LoadScene, recursive(), the camera
+// globals, CalculateLightsIntensity(), RandomPositionInPixel() and every
+// Material::Shade.  libc rand() is interposed by the counter stream of
+// include/bhrt_rng.h (sequential mode), reset per (pixel, sample).
+//
+// What this file restates (because the reference has it inline in BeginRender /
+// PathTracing and it cannot be called separately): the camera frame
+// (Main.cpp:179-192), the per-sample body of PathTracing (Main.cpp:145-168), the
+// average / gamma / Color24 store (Main.cpp:170,220-230).  Everything else is the
+// reference's own code.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+#include <string>
+#include <map>
+#include <atomic>
+#include <algorithm>
+#include <iostream>
+#include <sstream>
+#include <limits>
+#include <cassert>
+#include <cstdint>
+#include <omp.h>
+#include <xmmintrin.h>
+#include <emmintrin.h>
+
+#include "../../include/bhrt_rng.h"
+
+// read-only access to private state for the scene dump (layout is unaffected)
+#define private public
+#define protected public
+#include "Scenes/scene.h"
+#include "Objects/objects.h"
+#include "Lights/lights.h"
+#include "Materials/materials.h"
+#include "Textures/texture.h"
+#include "cyPhotonMap.h"
+#undef private
+#undef protected
+
+#define main bhrt_reference_main
+#include "Main.cpp"
+#undef main
+
+// ---------------------------------------------------------------- rand() interposition
+static uint32_t g_key = 0, g_ctr = 0;
+static unsigned long long g_draws = 0;
+extern "C" int rand(void) { g_draws++; return bhrt_rand31(g_key, g_ctr++); }
+
+// ---------------------------------------------------------------- helpers
+static std::vector<const Node *> g_nodes; // DFS pre-order, root excluded
+static std::map<const Node *, int> g_nodeIndex;
+static std::vector<int> g_parent, g_depth;
+
+static void Flatten(const Node *n, int parent, int depth)
+{
+    for (int i = 0; i < n->GetNumChild(); i++) {
+        const Node *c = n->GetChild(i);
+        int idx = (int)g_nodes.size();
+        g_nodes.push_back(c);
+        g_nodeIndex[c] = idx;
+        g_parent.push_back(parent);
+        g_depth.push_back(depth);
+        Flatten(c, idx, depth + 1);
+    }
+}
+
+template <class T> static void WriteFile(const std::string &path, const std::vector<T> &v)
+{
+    FILE *fp = fopen(path.c_str(), "wb");
+    if (!fp) { fprintf(stderr, "cannot write %s\n", path.c_str()); exit(2); }
+    if (!v.empty()) fwrite(v.data(), sizeof(T), v.size(), fp);
+    fclose(fp);
+}
+template <class T> static std::vector<T> ReadFile(const std::string &path)
+{
+    std::vector<T> v;
+    FILE *fp = fopen(path.c_str(), "rb");
+    if (!fp) { fprintf(stderr, "cannot read %s\n", path.c_str()); exit(2); }
+    fseek(fp, 0, SEEK_END);
+    long n = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    v.resize(n / sizeof(T));
+    if (n) { size_t got = fread(v.data(), 1, n, fp); (void)got; }
+    fclose(fp);
+    return v;
+}
+
+static void SetupCameraFrame() // Main.cpp:179-192
+{
+    float aor = camera.imgWidth / (float)camera.imgHeight;
+    float tan_h_pov = tan(camera.fov / 2 * PI / 180.0);
+    float l = camera.focaldist;
+    float h = 2 * l * tan_h_pov;
+    float w = aor * h;
+    camZAxis = -camera.dir;
+    camYAxis = camera.up;
+    camXAxis = camYAxis.Cross(camZAxis);
+    topLeft = camera.pos - camZAxis * l + camYAxis * h / 2 - camXAxis * w / 2;
+    dd_x = camXAxis * w / camera.imgWidth;
+    dd_y = camYAxis * h / camera.imgHeight;
+}
+
+static void PushHit(std::vector<int> &oi, std::vector<float> &of, bool bHit, const HitInfo &h)
+{
+    oi.push_back(bHit && h.node ? g_nodeIndex[h.node] : -1);
+    oi.push_back(h.front ? 1 : 0);
+    of.push_back(h.z);
+    of.push_back(h.p.x); of.push_back(h.p.y); of.push_back(h.p.z);
+    of.push_back(h.N.x); of.push_back(h.N.y); of.push_back(h.N.z);
+    of.push_back(h.uvw.x); of.push_back(h.uvw.y); of.push_back(h.uvw.z);
+    for (int k = 0; k < 2; k++) { of.push_back(h.duvw[k].x); of.push_back(h.duvw[k].y); of.push_back(h.duvw[k].z); }
+}
+
+static int MaterialIndex(const Material *m)
+{
+    if (!m) return -1;
+    for (size_t i = 0; i < materials.size(); i++) if (materials[i] == m) return (int)i;
+    return -2;
+}
+
+static void DumpTexturedColor(std::vector<float> &f, const TexturedColor &tc)
+{
+    Color c = tc.GetColor();
+    f.push_back(c.r); f.push_back(c.g); f.push_back(c.b);
+    f.push_back(tc.GetTexture() ? 1.f : 0.f);
+}
+
+static void DumpScene(const std::string &prefix)
+{
+    std::vector<int> ni;
+    std::vector<float> nf;
+    std::vector<const TriObj *> meshes;
+    for (size_t k = 0; k < g_nodes.size(); k++) {
+        const Node *n = g_nodes[k];
+        int type = 0, meshid = -1;
+        const Object *o = n->GetNodeObj();
+        if (o) {
+            if (dynamic_cast<const Sphere *>(o)) type = 1;
+            else if (dynamic_cast<const Plane *>(o)) type = 2;
+            else if (const TriObj *t = dynamic_cast<const TriObj *>(o)) {
+                type = 3;
+                size_t m = 0;
+                for (; m < meshes.size(); m++) if (meshes[m] == t) break;
+                if (m == meshes.size()) meshes.push_back(t);
+                meshid = (int)m;
+            }
+        }
+        ni.push_back(g_parent[k]); ni.push_back(g_depth[k]); ni.push_back(type); ni.push_back(meshid);
+        ni.push_back(MaterialIndex(n->GetMaterial()));
+        const Matrix3f &tm = n->GetTransform();
+        const Matrix3f &itm = n->GetInverseTransform();
+        for (int i = 0; i < 9; i++) nf.push_back(tm.cell[i]);
+        nf.push_back(n->GetPosition().x); nf.push_back(n->GetPosition().y); nf.push_back(n->GetPosition().z);
+        for (int i = 0; i < 9; i++) nf.push_back(itm.cell[i]);
+    }
+    WriteFile(prefix + ".nodes_i32", ni);
+    WriteFile(prefix + ".nodes_f32", nf);
+
+    std::vector<float> cam = {camera.pos.x, camera.pos.y, camera.pos.z, camera.dir.x, camera.dir.y, camera.dir.z,
+                              camera.up.x, camera.up.y, camera.up.z, camera.fov, camera.focaldist,
+                              (float)camera.imgWidth, (float)camera.imgHeight,
+                              topLeft.x, topLeft.y, topLeft.z, dd_x.x, dd_x.y, dd_x.z, dd_y.x, dd_y.y, dd_y.z};
+    WriteFile(prefix + ".camera_f32", cam);
+
+    std::vector<float> lf;
+    for (size_t i = 0; i < lights.size(); i++) {
+        Light *l = lights[i];
+        if (AmbientLight *a = dynamic_cast<AmbientLight *>(l)) {
+            lf.push_back(0); lf.push_back(a->intensity.r); lf.push_back(a->intensity.g); lf.push_back(a->intensity.b);
+            lf.push_back(0); lf.push_back(0); lf.push_back(0); lf.push_back(0);
+        } else if (DirectLight *d = dynamic_cast<DirectLight *>(l)) {
+            lf.push_back(1); lf.push_back(d->intensity.r); lf.push_back(d->intensity.g); lf.push_back(d->intensity.b);
+            lf.push_back(d->direction.x); lf.push_back(d->direction.y); lf.push_back(d->direction.z); lf.push_back(0);
+        } else if (PointLight *p = dynamic_cast<PointLight *>(l)) {
+            lf.push_back(2); lf.push_back(p->intensity.r); lf.push_back(p->intensity.g); lf.push_back(p->intensity.b);
+            lf.push_back(p->position.x); lf.push_back(p->position.y); lf.push_back(p->position.z); lf.push_back(p->size);
+        }
+    }
+    lf.push_back(allLightIntensity);
+    WriteFile(prefix + ".lights_f32", lf);
+
+    std::vector<float> mf;
+    for (size_t i = 0; i < materials.size(); i++) {
+        MtlBlinn *m = dynamic_cast<MtlBlinn *>(materials[i]);
+        if (!m) { for (int k = 0; k < 26; k++) mf.push_back(-1.f); continue; }
+        DumpTexturedColor(mf, m->diffuse);
+        DumpTexturedColor(mf, m->specular);
+        DumpTexturedColor(mf, m->refraction);
+        DumpTexturedColor(mf, m->reflection);
+        DumpTexturedColor(mf, m->emission);
+        mf.push_back(m->glossiness);
+        mf.push_back(m->absorption.r); mf.push_back(m->absorption.g); mf.push_back(m->absorption.b);
+        mf.push_back(m->ior);
+        mf.push_back(m->refractionGlossiness);
+    }
+    WriteFile(prefix + ".materials_f32", mf);
+
+    for (size_t m = 0; m < meshes.size(); m++) {
+        const TriObj *t = meshes[m];
+        char tag[64];
+        snprintf(tag, sizeof tag, ".mesh%d", (int)m);
+        std::string mp = prefix + tag;
+        std::vector<float> v, vn, vt;
+        std::vector<unsigned> f, fn, ft;
+        for (unsigned i = 0; i < t->NV(); i++) { v.push_back(t->V(i).x); v.push_back(t->V(i).y); v.push_back(t->V(i).z); }
+        for (unsigned i = 0; i < t->NVN(); i++) { vn.push_back(t->VN(i).x); vn.push_back(t->VN(i).y); vn.push_back(t->VN(i).z); }
+        for (unsigned i = 0; i < t->NVT(); i++) { vt.push_back(t->VT(i).x); vt.push_back(t->VT(i).y); vt.push_back(t->VT(i).z); }
+        for (unsigned i = 0; i < t->NF(); i++) {
+            for (int k = 0; k < 3; k++) f.push_back(t->F(i).v[k]);
+            if (t->fn) for (int k = 0; k < 3; k++) fn.push_back(t->FN(i).v[k]);
+            if (t->ft) for (int k = 0; k < 3; k++) ft.push_back(t->FT(i).v[k]);
+        }
+        WriteFile(mp + ".v_f32", v); WriteFile(mp + ".vn_f32", vn); WriteFile(mp + ".vt_f32", vt);
+        WriteFile(mp + ".f_u32", f); WriteFile(mp + ".fn_u32", fn); WriteFile(mp + ".ft_u32", ft);
+        // BVH: walk the node array from the root (id 1) to find its extent
+        const cyBVHTriMesh &bvh = t->bvh;
+        unsigned maxId = 1;
+        std::vector<unsigned> stack = {1};
+        while (!stack.empty()) {
+            unsigned id = stack.back(); stack.pop_back();
+            if (id > maxId) maxId = id;
+            if (!bvh.IsLeafNode(id)) { stack.push_back(bvh.GetFirstChildNode(id)); stack.push_back(bvh.GetSecondChildNode(id)); }
+        }
+        std::vector<float> bb((maxId + 1) * 6, 0.f);
+        std::vector<unsigned> bd(maxId + 1, 0u);
+        for (unsigned id = 1; id <= maxId; id++) {
+            const float *b = bvh.GetNodeBounds(id);
+            for (int k = 0; k < 6; k++) bb[id * 6 + k] = b[k];
+            bd[id] = bvh.nodes[id].data;
+        }
+        std::vector<unsigned> el(bvh.elements, bvh.elements + t->NF());
+        WriteFile(mp + ".bvh_f32", bb); WriteFile(mp + ".bvh_u32", bd); WriteFile(mp + ".elems_u32", el);
+        std::vector<float> bounds = {t->GetBoundMin().x, t->GetBoundMin().y, t->GetBoundMin().z,
+                                     t->GetBoundMax().x, t->GetBoundMax().y, t->GetBoundMax().z};
+        WriteFile(mp + ".bounds_f32", bounds);
+    }
+}
+
+static void usage()
+{
+    fprintf(stderr,
+            "usage: ref_harness <scene.xml> <out_prefix> [--spp N] [--gi G] [--bounce B] [--seed S]\n"
+            "                   [--region x0 y0 x1 y1] [--rays file] [--shadow file] cmd...\n"
+            "  cmds: dump primary rays shadow render\n");
+    exit(2);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) usage();
+    const char *scene = argv[1];
+    std::string prefix = argv[2];
+    int spp = 1, gi = GIBounceCount, bounce = INTERNAL_REFLECTION_BOUNCE;
+    uint32_t seed = 0;
+    int rx0 = 0, ry0 = 0, rx1 = -1, ry1 = -1;
+    std::string raysFile, shadowFile;
+    std::vector<std::string> cmds;
+    for (int a = 3; a < argc; a++) {
+        std::string s = argv[a];
+        if (s == "--spp") spp = atoi(argv[++a]);
+        else if (s == "--gi") gi = atoi(argv[++a]);
+        else if (s == "--bounce") bounce = atoi(argv[++a]);
+        else if (s == "--seed") seed = (uint32_t)strtoul(argv[++a], 0, 10);
+        else if (s == "--region") { rx0 = atoi(argv[a + 1]); ry0 = atoi(argv[a + 2]); rx1 = atoi(argv[a + 3]); ry1 = atoi(argv[a + 4]); a += 4; }
+        else if (s == "--rays") raysFile = argv[++a];
+        else if (s == "--shadow") shadowFile = argv[++a];
+        else cmds.push_back(s);
+    }
+    omp_set_num_threads(1);
+    if (!LoadScene(scene)) return 1;
+    SetupCameraFrame();
+    CalculateLightsIntensity(); // Main.cpp:116-123 (sorts `lights`, sums allLightIntensity)
+    Flatten(&rootNode, -1, 1);
+    const int W = camera.imgWidth, H = camera.imgHeight;
+    if (rx1 < 0) { rx1 = W; ry1 = H; }
+
+    for (const std::string &cmd : cmds) {
+        if (cmd == "dump") {
+            DumpScene(prefix);
+        } else if (cmd == "primary") {
+            // rays through the reference's pixel "centre" (= corner, Main.cpp:145), no jitter
+            std::vector<int> oi; std::vector<float> of;
+            for (int j = 0; j < H; j++)
+                for (int i = 0; i < W; i++) {
+                    Vec3f pixelCenter = topLeft + (i + 1 / 2) * dd_x - (j + 1 / 2) * dd_y;
+                    Ray ray = Ray(camera.pos, pixelCenter - camera.pos);
+                    bool bHit = false;
+                    HitInfo h = HitInfo();
+                    recursive(&rootNode, ray, h, bHit, HIT_FRONT);
+                    PushHit(oi, of, bHit, h);
+                }
+            WriteFile(prefix + ".primary_i32", oi);
+            WriteFile(prefix + ".primary_f32", of);
+        } else if (cmd == "rays") {
+            std::vector<float> in = ReadFile<float>(raysFile); // N x 7: o, d, hitSide
+            std::vector<int> oi; std::vector<float> of;
+            for (size_t r = 0; r + 6 < in.size(); r += 7) {
+                Ray ray(Vec3f(in[r], in[r + 1], in[r + 2]), Vec3f(in[r + 3], in[r + 4], in[r + 5]));
+                bool bHit = false;
+                HitInfo h = HitInfo();
+                recursive(&rootNode, ray, h, bHit, (int)in[r + 6]);
+                PushHit(oi, of, bHit, h);
+            }
+            WriteFile(prefix + ".rays_i32", oi);
+            WriteFile(prefix + ".rays_f32", of);
+        } else if (cmd == "shadow") {
+            std::vector<float> in = ReadFile<float>(shadowFile); // N x 7: o, d, t_max
+            std::vector<float> out;
+            struct Probe : public GenLight { // GenLight::Shadow is protected/static (lights.h:24)
+                Color Illuminate(Vec3f const &, Vec3f const &) const { return Color(0, 0, 0); }
+                Vec3f Direction(Vec3f const &) const { return Vec3f(0, 0, 0); }
+                float GetIntensity() const { return 0; }
+                static float S(Ray r, float t) { return Shadow(r, t); }
+            };
+            for (size_t r = 0; r + 6 < in.size(); r += 7) {
+                Ray ray(Vec3f(in[r], in[r + 1], in[r + 2]), Vec3f(in[r + 3], in[r + 4], in[r + 5]));
+                out.push_back(Probe::S(ray, in[r + 6]));
+            }
+            WriteFile(prefix + ".shadow_f32", out);
+        } else if (cmd == "render") {
+            // per-sample body of PathTracing (Main.cpp:145-168) with rand() reset per (pixel, sample)
+            const int rw = rx1 - rx0, rh = ry1 - ry0;
+            std::vector<float> samples((size_t)rw * rh * spp * 3);
+            std::vector<float> radiance((size_t)rw * rh * 3);
+            std::vector<unsigned char> rgb((size_t)rw * rh * 3);
+            std::vector<unsigned> draws((size_t)rw * rh * spp);
+            const float pixelLen = dd_x.Length();
+            for (int j = ry0; j < ry1; j++)
+                for (int i = rx0; i < rx1; i++) {
+                    Vec3f pixelCenter = topLeft + (i + 1 / 2) * dd_x - (j + 1 / 2) * dd_y;
+                    Color colorSum = Color::Black();
+                    size_t pix = (size_t)(j - ry0) * rw + (i - rx0);
+                    for (int s = 0; s < spp; s++) {
+                        g_key = bhrt_sample_key(seed, (uint32_t)(j * W + i), (uint32_t)s);
+                        g_ctr = 0;
+                        Ray ray = Ray(camera.pos, RandomPositionInPixel(pixelCenter, pixelLen) - camera.pos);
+                        bool bHit = false;
+                        HitInfo h = HitInfo();
+                        recursive(&rootNode, ray, h, bHit, HIT_FRONT);
+                        Color c;
+                        if (bHit) c = h.node->GetMaterial()->Shade(ray, h, lights, bounce, gi);
+                        else {
+                            Vec3f bguvw = Vec3f((float)i / camera.imgWidth, (float)j / camera.imgHeight, 0.0f);
+                            c = background.Sample(bguvw);
+                        }
+                        colorSum += c;
+                        float *o = &samples[(pix * spp + s) * 3];
+                        o[0] = c.r; o[1] = c.g; o[2] = c.b;
+                        draws[pix * spp + s] = g_ctr;
+                    }
+                    Color outColor = colorSum / spp; // Main.cpp:170 (int divisor -> float)
+                    radiance[pix * 3 + 0] = outColor.r; radiance[pix * 3 + 1] = outColor.g; radiance[pix * 3 + 2] = outColor.b;
+                    Color g = Color::Black(); // Main.cpp:220-226
+                    const float inverseGama = 1 / 2.2f;
+                    g.r = pow(outColor.r, inverseGama);
+                    g.g = pow(outColor.g, inverseGama);
+                    g.b = pow(outColor.b, inverseGama);
+                    Color24 q = Color24(g); // Main.cpp:230
+                    rgb[pix * 3 + 0] = q.r; rgb[pix * 3 + 1] = q.g; rgb[pix * 3 + 2] = q.b;
+                }
+            WriteFile(prefix + ".samples_f32", samples);
+            WriteFile(prefix + ".radiance_f32", radiance);
+            WriteFile(prefix + ".rgb8", rgb);
+            WriteFile(prefix + ".draws_u32", draws);
+        } else {
+            usage();
+        }
+    }
+    fprintf(stderr, "ref_harness: done (%llu rand() draws)\n", g_draws);
+    return 0;
+}
