@@ -1,0 +1,204 @@
+"""bhraytracer_amd — ctypes binding of libbhrt.so (include/bhrt.h).
+
+Plumbing only: the product is the C-ABI library (host front-end in C++ + hand-written gfx950
+HIP kernels).  This module loads it for the tests, bench.py and tools, and fails loudly when
+the library has not been built — there is no Python or CPU fallback for the render path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .flat import FlatView
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbhrt.so")
+
+SIDE_FRONT, SIDE_BACK, SIDE_BOTH = 1, 2, 3
+
+
+class BhrtError(RuntimeError):
+    pass
+
+
+class Info(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32)] + [
+        (n, C.c_uint32) for n in ("n_nodes", "n_meshes", "n_triangles", "n_bvh_nodes", "n_materials", "n_lights",
+                                  "n_textures", "max_node_depth", "max_bvh_depth")] + [
+        ("flat_bytes", C.c_uint64), ("n_warnings", C.c_uint32)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("spp", C.c_int32), ("gi_bounces", C.c_int32), ("internal_bounces", C.c_int32), ("seed", C.c_uint32),
+                ("jitter", C.c_int32), ("gamma", C.c_int32), ("photon_map", C.c_int32),
+                ("rank", C.c_int32), ("world_size", C.c_int32), ("tile_size", C.c_int32),
+                ("samples_per_pass", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("shade_calls", C.c_uint64),
+                ("camera_samples", C.c_uint64), ("passes", C.c_uint32), ("wave_iterations", C.c_uint32),
+                ("seconds_total", C.c_double), ("seconds_trace_closest", C.c_double),
+                ("seconds_trace_shadow", C.c_double), ("seconds_shade", C.c_double), ("seconds_other", C.c_double),
+                ("launches_trace_closest", C.c_uint64), ("launches_trace_shadow", C.c_uint64),
+                ("reserved", C.c_double * 4)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+class Hits(C.Structure):
+    _fields_ = [("t", C.c_void_p), ("node", C.c_void_p), ("prim", C.c_void_p), ("front", C.c_void_p)]
+
+
+_lib = None
+
+# every symbol include/bhrt.h declares
+EXPORTS = [
+    "bhrt_last_error", "bhrt_default_opts", "bhrt_scene_load_xml", "bhrt_scene_free", "bhrt_scene_info",
+    "bhrt_scene_warning", "bhrt_scene_flat", "bhrt_scene_upload", "bhrt_device_count",
+    "bhrt_trace_closest_host", "bhrt_trace_closest_dev", "bhrt_trace_shadow_host", "bhrt_trace_shadow_dev",
+    "bhrt_render", "bhrt_render_dev", "bhrt_render_samples", "bhrt_photon_build", "bhrt_photon_gather_host",
+    "bhrt_photon_export", "bhrt_save_png",
+]
+
+
+def lib():
+    """Loads libbhrt.so; raises if it is missing (run `python -m bhraytracer_amd.build` first)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BhrtError(f"{LIB_PATH} not found: build it with `python -m bhraytracer_amd.build` "
+                            "(the render path has no fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.bhrt_last_error.restype = C.c_char_p
+        L.bhrt_scene_free.restype = None
+        L.bhrt_default_opts.restype = None
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise BhrtError(f"bhrt error {rc}: {lib().bhrt_last_error().decode(errors='replace')}")
+
+
+def default_opts(**kw) -> Opts:
+    o = Opts()
+    lib().bhrt_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().bhrt_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Scene:
+    """A loaded scene = the reference's LoadScene() globals behind one handle (Main.cpp:17-37,43)."""
+
+    def __init__(self, xml_path: str):
+        self._h = C.c_void_p()
+        _check(lib().bhrt_scene_load_xml(os.fsencode(xml_path), C.byref(self._h)))
+        self.info = Info()
+        _check(lib().bhrt_scene_info(self._h, C.byref(self.info)))
+        self._flat = None
+
+    def close(self):
+        if self._h:
+            lib().bhrt_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def width(self):
+        return self.info.width
+
+    @property
+    def height(self):
+        return self.info.height
+
+    def warnings(self):
+        out = []
+        for i in range(self.info.n_warnings):
+            s = C.c_char_p()
+            _check(lib().bhrt_scene_warning(self._h, i, C.byref(s)))
+            out.append(s.value.decode(errors="replace"))
+        return out
+
+    def flat_bytes(self) -> bytes:
+        if self._flat is None:
+            p, n = C.c_void_p(), C.c_uint64()
+            _check(lib().bhrt_scene_flat(self._h, C.byref(p), C.byref(n)))
+            self._flat = C.string_at(p, n.value)
+        return self._flat
+
+    def flat_view(self) -> FlatView:
+        return FlatView(self.flat_bytes())
+
+    def upload(self, device: int = 0):
+        _check(lib().bhrt_scene_upload(self._h, device))
+
+    # ---- hot path, host buffers -------------------------------------------------------------
+    def trace_closest(self, origins, dirs, hit_side=SIDE_FRONT):
+        """recursive() for n rays; origins/dirs: (n,3) float32. Returns dict of numpy arrays."""
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(dirs, np.float32)
+        n = o.shape[0]
+        soa = np.ascontiguousarray(np.concatenate([o.T, d.T], axis=0), np.float32)  # ox[n] oy[n] oz[n] dx..
+        t = np.empty(n, np.float32)
+        node = np.empty(n, np.int32)
+        prim = np.empty(n, np.int32)
+        front = np.empty(n, np.int32)
+        h = Hits(_ptr(t), _ptr(node), _ptr(prim), _ptr(front))
+        _check(lib().bhrt_trace_closest_host(self._h, _ptr(soa), int(hit_side), C.c_size_t(n), h))
+        return {"t": t, "node": node, "prim": prim, "front": front}
+
+    def trace_shadow(self, origins, dirs, tmax):
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(dirs, np.float32)
+        n = o.shape[0]
+        soa = np.ascontiguousarray(np.concatenate([o.T, d.T], axis=0), np.float32)
+        tm = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, np.float32), (n,)), np.float32)
+        vis = np.empty(n, np.float32)
+        _check(lib().bhrt_trace_shadow_host(self._h, _ptr(soa), _ptr(tm), C.c_size_t(n), _ptr(vis)))
+        return vis
+
+    def render(self, opts: Opts, want_radiance=True):
+        """BeginRender(): returns (rgb8 HxWx3 uint8, radiance HxWx3 float32 or None, Stats)."""
+        W, H = self.width, self.height
+        rgb = np.zeros((H, W, 3), np.uint8)
+        rad = np.zeros((H, W, 3), np.float32) if want_radiance else None
+        st = Stats()
+        _check(lib().bhrt_render(self._h, C.byref(opts), _ptr(rgb), _ptr(rad) if want_radiance else None, C.byref(st)))
+        return rgb, rad, st
+
+    def render_dev(self, opts: Opts, d_rgb8_ptr: int, d_radiance_ptr: int):
+        """Same with outputs left in HBM (raw device pointers, e.g. torch tensor .data_ptr())."""
+        st = Stats()
+        _check(lib().bhrt_render_dev(self._h, C.byref(opts), C.c_void_p(d_rgb8_ptr or None),
+                                     C.c_void_p(d_radiance_ptr or None), C.byref(st), None))
+        return st
+
+    def render_samples(self, opts: Opts, x0, y0, x1, y1):
+        out = np.zeros(((y1 - y0) * (x1 - x0), opts.spp, 3), np.float32)
+        st = Stats()
+        _check(lib().bhrt_render_samples(self._h, C.byref(opts), x0, y0, x1, y1, _ptr(out), C.byref(st)))
+        return out, st
+
+
+def save_png(path: str, rgb8: np.ndarray):
+    a = np.ascontiguousarray(rgb8, np.uint8)
+    _check(lib().bhrt_save_png(os.fsencode(path), _ptr(a), a.shape[1], a.shape[0]))

@@ -1,0 +1,59 @@
+"""Builds libbhrt.so (the C-ABI library: host front-end + gfx950 HIP kernels) in-tree.
+
+    python -m bhraytracer_amd.build            # or: from bhraytracer_amd.build import build; build()
+
+Host TUs are compiled with g++, kernels.hip with hipcc (--offload-arch=gfx950); both with
+-ffp-contract=off — bit-exact parity with the reference needs unfused IEEE single operations.
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only container.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libbhrt.so")
+
+HOST_SRCS = ["scene_host.cpp", "png_io.cpp", "capi_host.cpp"]
+HIP_SRCS = ["kernels.hip"]
+COMMON = ["-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+
+
+def _newer(src_list, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def _run(cmd):
+    print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OUT, exist_ok=True)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    objs = []
+    for s in HOST_SRCS:
+        src, obj = os.path.join(CSRC, s), os.path.join(OUT, s + ".o")
+        if force or _newer([src] + headers, obj):
+            _run(["g++"] + COMMON + ["-Wall", "-c", src, "-o", obj])
+        objs.append(obj)
+    for s in HIP_SRCS:
+        src, obj = os.path.join(CSRC, s), os.path.join(OUT, s + ".o")
+        if force or _newer([src] + headers, obj):
+            _run([hipcc, "--offload-arch=gfx950"] + COMMON + ["-Wno-unused-result", "-c", src, "-o", obj])
+        objs.append(obj)
+    if force or _newer(objs, LIB):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lz", "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

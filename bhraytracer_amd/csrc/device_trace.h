@@ -1,0 +1,353 @@
+// device_trace.h — device-side intersection and traversal for gfx950.
+//
+// Reproduces, decision for decision, the reference's closest-hit and any-hit walks
+// (all paths relative to /root/reference/BHRayTracer):
+//   recursive()                     Main.cpp:389-413          scene-graph DFS, later-wins ties
+//   Node::ToNodeCoords              Scenes/scene.h:490-496    per-level transform chain (never composed)
+//   Sphere/Plane::IntersectRay      Objects/Sphere/Sphere.cpp:8-75, Objects/Plane/Plane.cpp:8-77
+//   Box::IntersectRay               Objects/Box/Box.cpp:3-46  slab test by DIVISION
+//   TriObj::IntersectRay/TraceBVHNode/IntersectTriangle   Objects/TriObj/TriObj.cpp:17-39,68-270
+//   GenLight::Shadow/ShadowRayRecursive                   Lights/GenLight.cpp:10-69
+//   TriObj::ShadowRecursive/TraceBVHShadow                TriObj.cpp:41-66,272-307
+// but restructured for a GPU lane: no recursion, no per-lane stack.  The BVH walk is a
+// state machine over (node, depth, two trail bits per level) with parent links; only the
+// ray parameter, node, triangle id and side are produced here (hit attributes are recomputed
+// by the shading kernel from this compact record).
+// Must be compiled with -ffp-contract=off.
+#pragma once
+#include "device_types.h"
+#include "vecmath.h"
+
+namespace bhrt {
+
+#define BHRT_PERP 0.001745f     /* TriObj.cpp:12 */
+#define BHRT_TRI_BIAS 0.0001f   /* TriObj.cpp:9 */
+#define BHRT_SHADOW_BIAS 0.00001f /* GenLight.cpp:5 */
+
+struct Hit {
+    float t;
+    int node, prim, front;
+};
+
+__device__ inline V3 ld3(const float *p) { return v3(p[0], p[1], p[2]); }
+
+// Node::ToNodeCoords (scene.h:490-496): p' = itm*(p-pos); d' = itm*((p+d)-pos) - p'
+__device__ inline void to_node(const bhrt_xform &t, V3 &p, V3 &d)
+{
+    V3 pos = ld3(t.pos);
+    V3 np = mat_mul(t.itm, p - pos);
+    V3 nd = mat_mul(t.itm, (p + d) - pos) - np;
+    p = np;
+    d = nd;
+}
+// the same with rootNode's identity transformation (ShadowRayRecursive starts AT the root: GenLight.cpp:17)
+__device__ inline void to_node_identity(V3 &p, V3 &d)
+{
+    const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    V3 z = v3(0, 0, 0);
+    V3 np = mat_mul(I, p - z);
+    V3 nd = mat_mul(I, (p + d) - z) - np;
+    p = np;
+    d = nd;
+}
+// ray of node n's object space, through the chain of its ancestors (root excluded)
+__device__ inline void local_ray(const DevScene &S, int n, V3 &p, V3 &d)
+{
+    const int depth = S.nodes[n].depth;
+    const int32_t *ch = S.chain + (size_t)n * BHRT_MAX_NODE_DEPTH;
+    for (int k = 0; k < depth; k++) to_node(S.nodes[ch[k]].xf, p, d);
+}
+
+// Box::IntersectRay (Box.cpp:3-46).  The reference forms n.Dot(v) with axis vectors; the zero products only
+// affect the sign of a zero, which no comparison below can see, so the axis components are used directly.
+__device__ inline bool box_hit(const float *b, V3 o, V3 d, float t_max, float &t_min)
+{
+    float tz1 = (d.z != 0) ? (b[2] - o.z) / d.z : BHRT_BIGFLOAT;
+    float tz2 = (d.z != 0) ? (b[5] - o.z) / d.z : -BHRT_BIGFLOAT;
+    float ty1 = (d.y != 0) ? (b[1] - o.y) / d.y : BHRT_BIGFLOAT;
+    float ty2 = (d.y != 0) ? (b[4] - o.y) / d.y : -BHRT_BIGFLOAT;
+    float tx1 = (d.x != 0) ? (b[0] - o.x) / d.x : BHRT_BIGFLOAT;
+    float tx2 = (d.x != 0) ? (b[3] - o.x) / d.x : -BHRT_BIGFLOAT;
+    float tMin = fmax_cy(fmax_cy(fmin_cy(tx1, tx2), fmin_cy(ty1, ty2)), fmin_cy(tz1, tz2));
+    float tMax = fmin_cy(fmin_cy(fmax_cy(tx1, tx2), fmax_cy(ty1, ty2)), fmax_cy(tz1, tz2));
+    if (tMin <= tMax && tMin < t_max) { t_min = tMin; return true; }
+    return false;
+}
+
+// barycentric part of IntersectTriangle (TriObj.cpp:105-168), shared with the attribute recomputation
+__device__ inline bool tri_areas(V3 v0, V3 v1, V3 v2, V3 vN, V3 vX, float &a0, float &a1, float &a2)
+{
+    float ax = fabsf(vN.x), ay = fabsf(vN.y), az = fabsf(vN.z);
+    float p0x = 0, p0y = 0, p1x = 0, p1y = 0, p2x = 0, p2y = 0, pXx = 0, pXy = 0;
+    if (ax >= ay && ax >= az) { p0x = v0.y; p0y = v0.z; p1x = v1.y; p1y = v1.z; p2x = v2.y; p2y = v2.z; pXx = vX.y; pXy = vX.z; }
+    else if (ay >= ax && ay >= az) { p0x = v0.x; p0y = v0.z; p1x = v1.x; p1y = v1.z; p2x = v2.x; p2y = v2.z; pXx = vX.x; pXy = vX.z; }
+    else if (az >= ay && az >= ax) { p0x = v0.x; p0y = v0.y; p1x = v1.x; p1y = v1.y; p2x = v2.x; p2y = v2.y; pXx = vX.x; pXy = vX.y; }
+    // Vec2::Cross: (-y)*p.x + x*p.y (cyVector.h:260-262)
+    float e1x = p1x - pXx, e1y = p1y - pXy, e2x = p2x - pXx, e2y = p2y - pXy, e0x = p0x - pXx, e0y = p0y - pXy;
+    a0 = ((-e1y) * e2x + e1x * e2y) / 2.f;
+    a1 = ((-e2y) * e0x + e2x * e0y) / 2.f;
+    a2 = ((-e0y) * e1x + e0x * e1y) / 2.f;
+    if ((a2 < 0 || a1 < 0 || a0 < 0) && !(a0 < 0 && a1 < 0 && a2 < 0)) return false;
+    return true;
+}
+
+// TriObj::IntersectTriangle (TriObj.cpp:68-189) up to the accept decision; dlen = ray.dir.Length()
+__device__ inline bool tri_hit(const bhrt_tri &tr, V3 o, V3 d, float dlen, int side, float t_cur, float &t_out, int &front_out)
+{
+    V3 v0 = ld3(tr.v0), v1 = ld3(tr.v1), v2 = ld3(tr.v2);
+    V3 vN = cross(v1 - v0, v2 - v0);
+    float t_divisor = dot(vN, d);
+    if (t_divisor == 0) return false;
+    float perp = t_divisor / (length(vN) * dlen);
+    if (perp > -BHRT_PERP && perp < BHRT_PERP) return false;
+    float t = (dot(vN, v0) - dot(vN, o)) / t_divisor;
+    if (t <= 0 || t > t_cur) return false;
+    bool hitFront = t_divisor < 0;
+    if (!hitFront && side == BHRT_HIT_FRONT) return false;
+    else if (hitFront && side == BHRT_HIT_BACK) return false;
+    V3 vX = o + t * d;
+    float a0, a1, a2;
+    if (!tri_areas(v0, v1, v2, vN, vX, a0, a1, a2)) return false;
+    t_out = t;
+    front_out = hitFront ? 1 : 0;
+    return true;
+}
+
+struct MeshRef {
+    const bhrt_bvh_node *bvh;
+    const uint32_t *elems;
+    const bhrt_tri *tris;
+};
+__device__ inline MeshRef mesh_ref(const DevScene &S, int mi)
+{
+    const bhrt_mesh &m = S.meshes[mi];
+    MeshRef r;
+    r.bvh = (const bhrt_bvh_node *)(S.blob + m.off_bvh);
+    r.elems = (const uint32_t *)(S.blob + m.off_elems);
+    r.tris = (const bhrt_tri *)(S.blob + m.off_tris);
+    return r;
+}
+
+// TriObj::IntersectRay + TraceBVHNode (TriObj.cpp:17-39,192-270) as a stackless state machine.
+//   descending into a node: leaf -> test its <=4 triangles in order; inner -> test both child boxes with
+//   t_max = current hit, none hit -> "return false", else go to the nearer child (child1 iff tmin1 < tmin2).
+//   ascending from a child with its return value r:
+//     from the FIRST-visited child: r true  -> the sibling is visited only if its box is hit with
+//                                              t_max = current hit (== `tempHitInfo.z > tmin_far`, TriObj.cpp:235,255);
+//                                    r false -> the sibling is visited unconditionally, even if its box
+//                                              was missed (TriObj.cpp:245-248,263-266)
+//     from the SECOND-visited child: return (first child's r) ? true : r
+//   children are adjacent and the first child's id is even (cyBVH.h:281-291), so sibling = id ^ 1.
+// Trail: bit (depth-1) of inFar / nearHit per level; depth <= 64 is checked at upload.
+__device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront)
+{
+    float tm;
+    if (!box_hit(M.bvh[1].b, o, d, ht, tm)) return false;
+    const float dlen = length(d);
+    uint32_t cur = 1;
+    int depth = 0;
+    uint64_t inFar = 0, nearHit = 0;
+    bool desc = true, r = false, any = false;
+    while (true) {
+        if (desc) {
+            const uint32_t data = M.bvh[cur].data;
+            if (data & 0x80000000u) {
+                const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
+                r = false;
+                for (uint32_t i = 0; i < count; i++) {
+                    const uint32_t face = M.elems[off + i];
+                    float t;
+                    int fr;
+                    if (tri_hit(M.tris[face], o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)face; hfront = fr; r = true; }
+                }
+                any |= r;
+                desc = false;
+            } else {
+                const uint32_t c1 = data & 0x7fffffffu;
+                float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
+                bool b1 = box_hit(M.bvh[c1].b, o, d, ht, tmin1);
+                bool b2 = box_hit(M.bvh[c1 + 1].b, o, d, ht, tmin2);
+                if (!b1 && !b2) { r = false; desc = false; }
+                else {
+                    depth++;
+                    const uint64_t bit = 1ull << (depth - 1);
+                    inFar &= ~bit;
+                    nearHit &= ~bit;
+                    cur = (tmin1 < tmin2) ? c1 : c1 + 1;
+                }
+            }
+        } else {
+            if (depth == 0) break;
+            const uint64_t bit = 1ull << (depth - 1);
+            const uint32_t sib = cur ^ 1u;
+            if (!(inFar & bit)) {
+                if (r) {
+                    nearHit |= bit;
+                    float tmf;
+                    if (box_hit(M.bvh[sib].b, o, d, ht, tmf)) { inFar |= bit; cur = sib; desc = true; }
+                    else { cur = M.bvh[cur].parent; depth--; /* r stays true */ }
+                } else {
+                    inFar |= bit;
+                    cur = sib;
+                    desc = true;
+                }
+            } else {
+                r = (nearHit & bit) ? true : r;
+                cur = M.bvh[cur].parent;
+                depth--;
+            }
+        }
+    }
+    return any;
+}
+
+// TriObj::ShadowRecursive + TraceBVHShadow (TriObj.cpp:41-66,272-307): pre-order walk (child1 then child2 — the
+// evaluation order of `A | B` in the g++ build of the reference), both children visited unless NEITHER box is hit,
+// stops at the first leaf that reports a front-face hit; the range test is applied to that hit only.
+__device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
+{
+    float tm;
+    if (!box_hit(M.bvh[1].b, o, d, BHRT_BIGFLOAT, tm)) return false;
+    const float dlen = length(d);
+    uint32_t cur = 1;
+    int depth = 0;
+    bool desc = true, found = false;
+    float t_min = BHRT_BIGFLOAT;
+    while (true) {
+        if (desc) {
+            const uint32_t data = M.bvh[cur].data;
+            if (data & 0x80000000u) {
+                const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
+                float ht = BHRT_BIGFLOAT; // fresh HitInfo per leaf (TriObj.cpp:280)
+                for (uint32_t i = 0; i < count; i++) {
+                    float t;
+                    int fr;
+                    if (tri_hit(M.tris[M.elems[off + i]], o, d, dlen, BHRT_HIT_FRONT, ht, t, fr)) { ht = t; found = true; t_min = t; }
+                }
+                if (found) break;
+                desc = false;
+            } else {
+                const uint32_t c1 = data & 0x7fffffffu;
+                float t1, t2;
+                bool b1 = box_hit(M.bvh[c1].b, o, d, BHRT_BIGFLOAT, t1);
+                bool b2 = box_hit(M.bvh[c1 + 1].b, o, d, BHRT_BIGFLOAT, t2);
+                if (!b1 && !b2) desc = false;
+                else { depth++; cur = c1; }
+            }
+        } else {
+            if (depth == 0) break;
+            if ((cur & 1u) == 0) { cur = cur | 1u; desc = true; } // child1 done -> child2
+            else { cur = M.bvh[cur].parent; depth--; }
+        }
+    }
+    return found && t_min > BHRT_TRI_BIAS && t_min < t_max;
+}
+
+// Sphere::IntersectRay accept decision (Sphere.cpp:8-50)
+__device__ inline bool sphere_hit(V3 oc, V3 dir, int side, float t_cur, float &t_out, int &front_out)
+{
+    float A = dot(dir, dir);
+    float B = 2 * dot(dir, oc);
+    float C = dot(oc, oc) - 1;
+    float DD = B * B - 4 * A * C;
+    if (!(DD > 0)) return false;
+    float sq = sqrtf(DD);
+    float t1 = (-B + sq) / (2 * A);
+    float t2 = (-B - sq) / (2 * A);
+    float t = BHRT_BIGFLOAT;
+    bool hitFront = true;
+    if (t1 < 0 && t2 < 0) return false;
+    else if (t1 * t2 <= 0) {
+        if (side == BHRT_HIT_FRONT) return false;
+        t = t1;
+        hitFront = false;
+    } else if (t1 > 0 && t2 > 0) {
+        if (side == BHRT_HIT_FRONT || side == BHRT_HIT_FRONT_AND_BACK) { t = t2; hitFront = true; }
+        else if (side == BHRT_HIT_BACK) { t = t1; hitFront = false; }
+    }
+    if (t_cur < t || t <= 0) return false;
+    t_out = t;
+    front_out = hitFront ? 1 : 0;
+    return true;
+}
+// Plane::IntersectRay accept decision (Plane.cpp:8-34)
+__device__ inline bool plane_hit(V3 p, V3 d, int side, float t_cur, float &t_out, int &front_out)
+{
+    if (d.z == 0.0f) return false;
+    float t = -p.z / d.z;
+    if (t <= 0 || t > t_cur) return false;
+    V3 x = p + t * d;
+    if (x.x < -1 || x.x > 1 || x.y < -1 || x.y > 1) return false;
+    bool hitFront = (dot(-d, v3(0, 0, 1)) > 0);
+    if (!hitFront && side == BHRT_HIT_FRONT) return false;
+    else if (hitFront && side == BHRT_HIT_BACK) return false;
+    t_out = t;
+    front_out = hitFront ? 1 : 0;
+    return true;
+}
+
+// recursive(&rootNode, ...) (Main.cpp:389-413): nodes in DFS pre-order, "t > hit" rejects so a later
+// equal-t candidate wins.
+__device__ inline void trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit &h)
+{
+    h.t = BHRT_BIGFLOAT; h.node = -1; h.prim = -1; h.front = 1;
+    for (int n = 0; n < S.n_nodes; n++) {
+        const int type = S.nodes[n].obj_type;
+        if (type == BHRT_OBJ_NONE) continue;
+        V3 lp = o, ld = d;
+        local_ray(S, n, lp, ld);
+        float t;
+        int fr;
+        if (type == BHRT_OBJ_SPHERE) {
+            if (sphere_hit(lp, ld, side, h.t, t, fr)) { h.t = t; h.node = n; h.prim = -1; h.front = fr; }
+        } else if (type == BHRT_OBJ_PLANE) {
+            if (plane_hit(lp, ld, side, h.t, t, fr)) { h.t = t; h.node = n; h.prim = -1; h.front = fr; }
+        } else {
+            MeshRef M = mesh_ref(S, S.nodes[n].mesh);
+            if (mesh_closest(M, lp, ld, side, h.t, h.prim, h.front)) h.node = n;
+        }
+    }
+}
+
+// GenLight::Shadow (GenLight.cpp:10-69).  The result is an OR over per-node tests that do not influence each
+// other, so nodes are tested in index order; each test is the reference's (including its quirks Q1-Q3).
+__device__ inline float trace_shadow(const DevScene &S, V3 o, V3 d, float t_max)
+{
+    V3 rp = o, rd = d;
+    to_node_identity(rp, rd); // rootNode's own ToNodeCoords
+    for (int n = 0; n < S.n_nodes; n++) {
+        const int type = S.nodes[n].obj_type;
+        if (type == BHRT_OBJ_NONE) continue;
+        const int depth = S.nodes[n].depth;
+        const int32_t *ch = S.chain + (size_t)n * BHRT_MAX_NODE_DEPTH;
+        V3 pp = rp, pd = rd; // ray in the PARENT's space (used by the plane test, Q1)
+        for (int k = 0; k + 1 < depth; k++) to_node(S.nodes[ch[k]].xf, pp, pd);
+        V3 lp = pp, ld = pd;
+        to_node(S.nodes[n].xf, lp, ld);
+        if (type == BHRT_OBJ_SPHERE) {
+            float A = dot(ld, ld);
+            float B = 2 * dot(ld, lp);
+            float C = dot(lp, lp) - 1;
+            float DD = B * B - 4 * A * C;
+            if (DD > 0) {
+                float sq = sqrtf(DD);
+                float t1 = (-B + sq) / (2 * A);
+                float t2 = (-B - sq) / (2 * A);
+                float t = fmin_cy(t1, t2);
+                if (!(t < 0) && t < t_max && t > BHRT_SHADOW_BIAS) return 0.f;
+            }
+        } else if (type == BHRT_OBJ_PLANE) {
+            float t = -lp.z / ld.z;
+            if (!(t < 0)) {
+                V3 x = pp + t * pd; // un-transformed ray
+                if (!(x.x < -1 || x.x > 1 || x.y < -1 || x.y > 1))
+                    if (t < t_max && t > BHRT_SHADOW_BIAS) return 0.f;
+            }
+        } else {
+            if (mesh_shadow(mesh_ref(S, S.nodes[n].mesh), lp, ld, t_max)) return 0.f;
+        }
+    }
+    return 1.f;
+}
+
+} // namespace bhrt

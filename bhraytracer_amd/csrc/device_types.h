@@ -1,0 +1,83 @@
+// device_types.h — data the HIP kernels see: the scene view over the HBM-resident flat blob and
+// the SoA wavefront buffers (ray queues, compact hits, shade frames).
+#pragma once
+#include <stdint.h>
+
+#include "bhrt_flat.h"
+
+namespace bhrt {
+
+// View over the uploaded flat scene (include/bhrt_flat.h); passed to kernels by value.
+struct DevScene {
+    const uint8_t *blob;
+    const bhrt_node *nodes;
+    const bhrt_mesh *meshes;
+    const bhrt_material *materials;
+    const bhrt_light *lights;
+    const bhrt_texmap *texmaps;
+    const bhrt_texture *textures;
+    const int32_t *chain; // n_nodes x BHRT_MAX_NODE_DEPTH: ancestors of node n from depth 1 down to n itself
+    int32_t n_nodes, n_lights;
+    float all_light_intensity;
+    bhrt_camera cam;
+    bhrt_texcolor background, environment;
+    float tapx[32], tapy[32]; // the 31 elliptic Halton taps of Texture::Sample (scene.h:322-329)
+};
+
+// continuation kinds of a closest-hit ray
+enum : uint32_t {
+    RK_CAMERA = 0,   // Main.cpp:153-158      frame = sample slot
+    RK_GI = 1,       // MtlBlinn.cpp:392-396  frame = shading frame that asked
+    RK_REFR_IN = 2,  // MtlBlinn.cpp:478-483
+    RK_REFR_OUT = 3  // MtlBlinn.cpp:524-526
+};
+// how a frame's result reaches its parent
+enum : uint32_t { FH_ROOT = 0, FH_GI = 1, FH_REFR_FRONT = 2, FH_REFR_OUT = 3 };
+// direct-light term state of a frame
+enum : uint32_t { DM_NONE = 0, DM_AMBIENT = 1, DM_DIRECT = 2, DM_POINT = 3, DM_POINT_ZERO = 4 };
+// frame flags
+enum : uint32_t { FF_CONST = 1u /* value in refr */, FF_HAS_REFR_COLOR = 2u };
+
+// Closest-hit ray queue (SoA, one array per field -> coalesced)
+struct RayQueue {
+    float *ox, *oy, *oz, *dx, *dy, *dz;
+    uint32_t *frame;   // owner (sample slot for RK_CAMERA)
+    uint32_t *meta;    // kind | side << 4 | bounce << 8
+    uint32_t *rng_ctr; // draw counter of the owner's refraction-section stream (glossy refraction chains)
+};
+struct HitBuf {
+    float *t;
+    int32_t *node, *prim, *front;
+};
+struct ShadowQueue {
+    float *ox, *oy, *oz, *dx, *dy, *dz, *tmax;
+    uint32_t *frame;
+};
+// One MtlBlinn::Shade invocation (MtlBlinn.cpp:89-138) awaiting its sub-terms
+struct Frames {
+    uint32_t *parent;  // parent frame, or sample slot when how == FH_ROOT
+    uint32_t *info;    // how | dmode << 3 | light << 8 | flags << 16 | material << 20 (12 bits)
+    uint32_t *info2;   // (gi + 64) | bounce << 8
+    uint32_t *skey;    // sample key (include/bhrt_rng.h)
+    uint64_t *code;    // shade-call path code
+    float *mult;       // 3: factor applied when delivering to the parent (GI: kd/ks sample; REFR_OUT: refraction*absorption)
+    float *refr;       // 3: refraction term (MtlBlinn.cpp:117)
+    float *gi;         // 3: GI term (:124)
+    float *gi_mult;    // 3: (useSpecular ? specular : diffuse).Sample at this frame's hit (:406,417)
+    float *brdf;       // 3: brdfXCosTheta (:325)
+    float *refr_color; // 3: (1-F)*refraction (:117)
+    float *rr;         // squared distance to the point light (PointLight.cpp:10-11)
+    float *vis;        // Shadow() result (GenLight.cpp:10-13)
+    float *caustic;    // 3: photon-map term brdf*irrad (:329-342), zero when off
+};
+
+struct Counters {
+    uint32_t n_next;    // rays pushed to the next closest-hit queue
+    uint32_t n_shadow;  // rays pushed to the shadow queue
+    uint32_t n_frames;  // frames allocated so far in this pass
+    uint32_t overflow;  // set when a capacity was exceeded
+    uint32_t n_shade;   // Shade() evaluations (stats)
+    uint32_t pad[3];
+};
+
+} // namespace bhrt

@@ -1,0 +1,983 @@
+// kernels.hip — the MI355X (gfx950) render path: wavefront path tracing over SoA buffers in HBM.
+//
+// One launch of each kernel processes one "wave step" of all paths in flight:
+//   k_camera_rays   Main.cpp:132-153,179-192   one lane per (pixel, sample) -> closest-hit ray queue
+//   k_trace_closest Main.cpp:389-413 + Objects/* ordered scene-graph + BVH closest hit -> compact hits
+//   k_shade         MtlBlinn.cpp:89-589        one lane per traced ray: rebuilds the HitInfo, evaluates one
+//                                              Shade() entry or one refraction-chain step, emits <=2 closest rays,
+//                                              <=1 shadow ray, <=1 new shading frame (wave ballot + prefix-sum
+//                                              compaction, one atomic per wave and queue)
+//   k_trace_shadow  GenLight.cpp:10-69         any-hit -> visibility into the owning frame
+//   k_combine       MtlBlinn.cpp:117-137,343,431,470,511,539  folds finished frames into their parents, deepest
+//                                              wave step first (the per-level clamps forbid a running throughput)
+//   k_resolve       Main.cpp:170,220-230       in-order sample sum, /spp, gamma, Color24
+// The recursion of the reference becomes: ray kinds (continuations) + a tree of shading frames.
+// No CPU fallback: every entry point fails when there is no usable HIP device.
+#include <hip/hip_runtime.h>
+
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "bhrt.h"
+#include "device_shade.h"
+#include "scene_internal.h"
+
+namespace bhrt {
+
+#define HIP_CHECK(expr)                                                                                        \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            SetError(std::string(#expr) + ": " + hipGetErrorString(e_));                                       \
+            return BHRT_ERR_HIP;                                                                               \
+        }                                                                                                      \
+    } while (0)
+
+constexpr int kBlock = 256;
+
+struct PassInfo {
+    int32_t W, H, tile, tiles_x, tiles_y, rank, world;
+    uint32_t q0;       // first owned-pixel index of this pass
+    uint32_t n_pixels; // owned pixels in this pass (incl. out-of-image pixels of edge tiles)
+    int32_t spp;
+    uint32_t seed;
+    int32_t jitter, gamma;
+};
+struct RenderParams {
+    int32_t internal_bounces, gi_bounces;
+    uint32_t cap_rays, cap_shadow, cap_frames;
+    int32_t photon;
+};
+
+// owned-pixel index q -> image coordinates; tiles are dealt round-robin to ranks
+__device__ inline bool pixel_of(const PassInfo &P, uint32_t q, int &i, int &j)
+{
+    const uint32_t tp = (uint32_t)(P.tile * P.tile);
+    const uint32_t k = q / tp, within = q % tp;
+    const uint32_t tile_id = (uint32_t)P.rank + k * (uint32_t)P.world;
+    const uint32_t ty = tile_id / (uint32_t)P.tiles_x, tx = tile_id % (uint32_t)P.tiles_x;
+    i = (int)(tx * P.tile + within % P.tile);
+    j = (int)(ty * P.tile + within / P.tile);
+    return ty < (uint32_t)P.tiles_y && i < P.W && j < P.H;
+}
+
+// wave64 compaction: ballot + prefix popcount, one atomic per wave (convergent call sites only)
+__device__ inline uint32_t wave_alloc(uint32_t *counter, bool pred)
+{
+    const uint64_t mask = __ballot(pred);
+    uint32_t idx = 0xffffffffu;
+    if (mask) {
+        const uint32_t lane = __lane_id();
+        const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        const int leader = __ffsll((long long)mask) - 1;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader);
+        idx = base + prefix;
+    }
+    return idx;
+}
+
+__device__ inline void put_ray(const RayQueue &q, uint32_t i, V3 o, V3 d, uint32_t frame, uint32_t meta, uint32_t ctr)
+{
+    q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z; q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
+    q.frame[i] = frame; q.meta[i] = meta; q.rng_ctr[i] = ctr;
+}
+__device__ inline uint32_t make_meta(uint32_t kind, uint32_t side, int bounce) { return kind | (side << 4) | ((uint32_t)(bounce & 0xff) << 8); }
+__device__ inline void st3(float *a, uint32_t i, V3 v) { a[3 * (size_t)i] = v.x; a[3 * (size_t)i + 1] = v.y; a[3 * (size_t)i + 2] = v.z; }
+__device__ inline V3 ld3i(const float *a, uint32_t i) { return v3(a[3 * (size_t)i], a[3 * (size_t)i + 1], a[3 * (size_t)i + 2]); }
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_camera_rays(DevScene S, PassInfo P, RayQueue q, Counters *cnt)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = P.n_pixels * (uint32_t)P.spp;
+    bool valid = idx < total;
+    int i = 0, j = 0;
+    uint32_t s = 0;
+    if (valid) {
+        const uint32_t q_local = idx / (uint32_t)P.spp;
+        s = idx % (uint32_t)P.spp;
+        valid = pixel_of(P, P.q0 + q_local, i, j);
+    }
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
+    if (valid) {
+        // PathTracing(), Main.cpp:145: pixel "centre" = corner because 1/2 == 0
+        const V3 topLeft = ld3(S.cam.top_left), ddx = ld3(S.cam.dd_x), ddy = ld3(S.cam.dd_y), pos = ld3(S.cam.pos);
+        V3 target = (topLeft + (float)i * ddx) - (float)j * ddy;
+        if (P.jitter) { // RandomPositionInPixel, Main.cpp:132-139: two raw rand() draws in double
+            const float pixelLen = length(ddx);
+            const V3 ux = normalized(ddx), uy = normalized(ddy);
+            const uint32_t key = bhrt_sample_key(P.seed, (uint32_t)(j * P.W + i), s);
+            float fx = (float)(((double)bhrt_rand31(key, 0) / (BHRT_RAND_MAX)) * 2 - 1);
+            target = target + ((ux * fx) * pixelLen) / 2.f;
+            float fy = (float)(((double)bhrt_rand31(key, 1) / (BHRT_RAND_MAX)) * 2 - 1);
+            target = target + ((uy * fy) * pixelLen) / 2.f;
+        }
+        o = pos;
+        d = target - pos;
+    }
+    const uint32_t slot = wave_alloc(&cnt->n_next, valid);
+    if (valid) put_ray(q, slot, o, d, idx, make_meta(RK_CAMERA, BHRT_HIT_FRONT, 0), 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// meta == nullptr: every ray uses `uniform_side` (public bhrt_trace_closest_*)
+__global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, RayQueue q, uint32_t n, int uniform_side, HitBuf h)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]), d = v3(q.dx[i], q.dy[i], q.dz[i]);
+    const int side = q.meta ? (int)((q.meta[i] >> 4) & 3u) : uniform_side;
+    Hit hit;
+    trace_closest(S, o, d, side, hit);
+    h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front;
+}
+
+// frame == nullptr: visibility goes to vis[i] (public bhrt_trace_shadow_*), else to vis[frame[i]]
+__global__ void __launch_bounds__(kBlock) k_trace_shadow(DevScene S, ShadowQueue q, uint32_t n, float *vis)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]), d = v3(q.dx[i], q.dy[i], q.dz[i]);
+    const float v = trace_shadow(S, o, d, q.tmax[i]);
+    vis[q.frame ? q.frame[i] : i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One Shade() entry (MtlBlinn.cpp:89-138): fills frame f, produces up to two closest rays and one shadow ray.
+struct ShadeOut {
+    bool has_refr, has_gi, has_shadow;
+    V3 ro, rd; uint32_t rmeta, rctr; // refraction ray
+    V3 go, gd;                       // GI ray
+    V3 so, sd; float stmax;          // shadow ray
+};
+
+__device__ inline void shade_entry(const DevScene &S, const RenderParams &R, const Frames &F, uint32_t f, V3 rayP, const Attr &a, int node,
+                                   int bounce, int gi, uint64_t code, uint32_t skey, ShadeOut &out)
+{
+    out.has_refr = out.has_gi = out.has_shadow = false;
+    const int mi = S.nodes[node].material;
+    uint32_t flags = 0, dmode = DM_NONE, light_idx = 0;
+    V3 zero = v3(0, 0, 0);
+    st3(F.refr, f, zero); st3(F.gi, f, zero); st3(F.brdf, f, zero); st3(F.gi_mult, f, zero); st3(F.refr_color, f, zero); st3(F.caustic, f, zero);
+    F.rr[f] = 1.f; F.vis[f] = 1.f;
+    if (mi < 0 || S.materials[mi].kind != BHRT_MTL_BLINN) {
+        // node without material: black (the reference dereferences null); empty MultiMtl: white (materials.h:71)
+        flags = FF_CONST;
+        st3(F.refr, f, (mi >= 0 && S.materials[mi].kind == BHRT_MTL_WHITE) ? v3(1, 1, 1) : zero);
+        F.info[f] = (F.info[f] & 7u) | (flags << 16);
+        return;
+    }
+    const bhrt_material &m = S.materials[mi];
+    V3 vN = normalized(a.N);
+    V3 vV = normalized(rayP - a.p);
+    float cosPhi1 = dot(vN, vV);
+    if (cosPhi1 > 1) cosPhi1 = 1;
+    if (cosPhi1 <= 0) cosPhi1 = 0;
+    const float ior = m.ior;
+    // pow(float,int) is double pow in the reference (MtlBlinn.cpp:107-109); device math: repeated product
+    double r0d = (double)((1 - ior) / (1 + ior));
+    float R0 = (float)(r0d * r0d);
+    double omc = (double)(1 - cosPhi1);
+    float fresnel = (float)(R0 + (1 - R0) * ((((omc * omc) * omc) * omc) * omc));
+    V3 refrC = ld3(m.refraction.color);
+    V3 fresSpec = clamp_white(ld3(m.specular.color) + fresnel * refrC);
+    bhrt_texcolor newSpecular = m.specular;
+    newSpecular.color[0] = fresSpec.x; newSpecular.color[1] = fresSpec.y; newSpecular.color[2] = fresSpec.z;
+    float refrGloss = 0;
+    if (m.glossiness > 50) refrGloss = m.glossiness;
+
+    // ---- refraction, PathTracing_Refraction (MtlBlinn.cpp:437-473)
+    V3 refraction = (1 - fresnel) * refrC;
+    if (bounce > 0 && !is_zero(refraction)) {
+        DRng g;
+        g.key = bhrt_section_key(skey, code, BHRT_SEC_REFRACTION);
+        g.ctr = 0;
+        float sinPhi1 = sqrtf(1 - cosPhi1 * cosPhi1);
+        float sinPhi2 = sinPhi1 / ior;
+        float cosPhi2 = sqrtf(1 - sinPhi2 * sinPhi2);
+        V3 vTn = (-cosPhi2) * vN;
+        V3 vNxV = cross(vN, vV);
+        V3 vTp = normalized(cross(vN, vNxV)) * sinPhi2;
+        V3 vT = vTn + vTp;
+        V3 vT_sampled = normalized(vT);
+        if (refrGloss > 0) {
+            float dotSign = 0;
+            int guard = 0;
+            while (dotSign >= 0 && guard++ < BHRT_MAXLOOP) {
+                float theta = 0;
+                vT_sampled = sample_along_light_direction(g, vT, refrGloss, theta);
+                dotSign = dot(vT_sampled, vN);
+            }
+        }
+        out.has_refr = true;
+        out.rd = normalized(vT_sampled);
+        out.ro = a.p - vN * BHRT_BIAS; // RefractionRecusive, MtlBlinn.cpp:478-480
+        out.rmeta = make_meta(RK_REFR_IN, BHRT_HIT_FRONT_AND_BACK, bounce);
+        out.rctr = g.ctr;
+        st3(F.refr_color, f, refraction);
+        flags |= FF_HAS_REFR_COLOR;
+    }
+    // ---- global illumination, PathTracing_GlobalIllumination (MtlBlinn.cpp:383-433)
+    const bool textured = m.diffuse.map >= 0 || newSpecular.map >= 0;
+    if (gi >= 0) {
+        DRng g;
+        g.key = bhrt_section_key(skey, code, BHRT_SEC_GI);
+        g.ctr = 0;
+        bool useSpecular;
+        out.gd = gi_direction(g, useSpecular, vN, vV, tc_max(m.diffuse.color), tc_max(newSpecular.color), m.glossiness);
+        out.go = a.p + vN * BHRT_BIAS;
+        out.has_gi = true;
+        const bhrt_texcolor &tcs = useSpecular ? newSpecular : m.diffuse;
+        st3(F.gi_mult, f, textured ? tc_sample_d(S, tcs, a.uvw, a.du, a.dv) : ld3(tcs.color));
+    }
+    // ---- direct light, PathTracing_DiffuseNSpecular (MtlBlinn.cpp:304-351)
+    if (S.n_lights > 0) {
+        DRng g;
+        g.key = bhrt_section_key(skey, code, BHRT_SEC_DIRECT);
+        g.ctr = 0;
+        float rnd = g.rnd01();
+        int li = 0;
+        while (rnd > gray3(S.lights[li].intensity) / S.all_light_intensity && li < S.n_lights - 1) li++;
+        const bhrt_light &light = S.lights[li];
+        light_idx = (uint32_t)li;
+        V3 vL = sample_in_light(g, m.diffuse.color, newSpecular.color, light, a.p, m.glossiness);
+        float cosTheta = dot(vL, vN);
+        if (cosTheta > 0) {
+            V3 vH = normalized(vL + vV);
+            // Illuminate: lights.h:32,50; PointLight.cpp:7-18
+            if (light.type == BHRT_LIGHT_AMBIENT) dmode = DM_AMBIENT;
+            else if (light.type == BHRT_LIGHT_DIRECT) {
+                dmode = DM_DIRECT;
+                out.has_shadow = true;
+                out.so = a.p; out.sd = -ld3(light.vec); out.stmax = BHRT_BIGFLOAT;
+            } else {
+                V3 centerDir = ld3(light.vec) - a.p;
+                float r = length(centerDir);
+                float rr = r * r;
+                if (rr == 0) dmode = DM_POINT_ZERO;
+                else {
+                    dmode = DM_POINT;
+                    F.rr[f] = rr;
+                    out.has_shadow = true;
+                    out.so = a.p;
+                    out.sd = light.size > 0 ? sample_along_normal(g, centerDir, light.size) : centerDir;
+                    out.stmax = 1;
+                }
+            }
+            V3 kd = textured ? tc_sample_d(S, m.diffuse, a.uvw, a.du, a.dv) : ld3(m.diffuse.color);
+            V3 ks = textured ? tc_sample_d(S, newSpecular, a.uvw, a.du, a.dv) : ld3(newSpecular.color);
+            st3(F.brdf, f, kd * cosTheta + ks * dm::powf_(dot(vH, vN), m.glossiness));
+        }
+    }
+    F.info[f] = (F.info[f] & 7u) | (dmode << 3) | (light_idx << 8) | (flags << 16) | ((uint32_t)(mi & 0xfff) << 20);
+}
+
+__global__ void __launch_bounds__(kBlock) k_shade(DevScene S, RenderParams R, PassInfo P, RayQueue qin, HitBuf hb, uint32_t n, RayQueue qout,
+                                                   ShadowQueue qs, Frames F, float *samples, Counters *cnt)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
+    uint32_t owner = 0, meta = 0, ctr = 0;
+    Hit hit = {BHRT_BIGFLOAT, -1, -1, 1};
+    if (active) {
+        o = v3(qin.ox[i], qin.oy[i], qin.oz[i]); d = v3(qin.dx[i], qin.dy[i], qin.dz[i]);
+        owner = qin.frame[i]; meta = qin.meta[i]; ctr = qin.rng_ctr[i];
+        hit.t = hb.t[i]; hit.node = hb.node[i]; hit.prim = hb.prim[i]; hit.front = hb.front[i];
+    }
+    const uint32_t kind = meta & 15u;
+    int bounce = (int)((meta >> 8) & 0xffu);
+    const bool is_hit = active && hit.node >= 0;
+    // which rays open a new Shade() frame
+    bool new_frame = false;
+    if (is_hit) {
+        if (kind == RK_CAMERA) new_frame = true;
+        else if (kind == RK_GI) new_frame = fabsf(hit.t) > BHRT_BIAS; // MtlBlinn.cpp:401
+        else if (kind == RK_REFR_IN) new_frame = hit.front != 0;      // MtlBlinn.cpp:507-510
+        else new_frame = true;                                        // RK_REFR_OUT, MtlBlinn.cpp:527-533
+    }
+    const uint32_t f = wave_alloc(&cnt->n_frames, new_frame);
+    if (new_frame && f >= R.cap_frames) { atomicOr(&cnt->overflow, 1u); new_frame = false; }
+
+    ShadeOut so;
+    so.has_refr = so.has_gi = so.has_shadow = false;
+    uint32_t ray_owner = owner; // frame that owns the rays emitted by this lane
+
+    if (new_frame) {
+        // ---- child (or root) frame bookkeeping
+        uint64_t code = 1;
+        uint32_t skey;
+        int gi;
+        uint32_t how;
+        V3 mult = v3(1, 1, 1);
+        if (kind == RK_CAMERA) {
+            int pi, pj;
+            pixel_of(P, P.q0 + owner / (uint32_t)P.spp, pi, pj);
+            skey = bhrt_sample_key(P.seed, (uint32_t)(pj * P.W + pi), owner % (uint32_t)P.spp);
+            gi = R.gi_bounces;
+            bounce = R.internal_bounces;
+            how = FH_ROOT;
+        } else {
+            const uint64_t pcode = F.code[owner];
+            skey = F.skey[owner];
+            const uint32_t pi2 = F.info2[owner];
+            gi = (int)(pi2 & 0xffu) - 64 - 1;
+            if (kind == RK_GI) {
+                code = pcode * 2 + 1;
+                how = FH_GI;
+                bounce = (int)((pi2 >> 8) & 0xffu); // Shade(GIRay, ..., o_bounceCount, gi-1): the parent's own bounce count
+                mult = ld3i(F.gi_mult, owner);
+            } else if (kind == RK_REFR_IN) {
+                code = pcode * 2;
+                how = FH_REFR_FRONT;
+            } else {
+                code = pcode * 2;
+                how = FH_REFR_OUT;
+                // Beer absorption, RefractionOut (MtlBlinn.cpp:529-533): refraction * absorptionFactor
+                const bhrt_material &pm = S.materials[(F.info[owner] >> 20) & 0xfffu];
+                V3 af = v3(dm::powf_(BHRT_EULER, -pm.absorption[0] * hit.t), dm::powf_(BHRT_EULER, -pm.absorption[1] * hit.t),
+                           dm::powf_(BHRT_EULER, -pm.absorption[2] * hit.t));
+                mult = ld3i(F.refr_color, owner) * af;
+            }
+        }
+        F.parent[f] = owner;
+        F.info[f] = how;
+        F.info2[f] = (uint32_t)(gi + 64) | ((uint32_t)(bounce & 0xff) << 8);
+        F.skey[f] = skey;
+        F.code[f] = code;
+        st3(F.mult, f, mult);
+        const int mi = S.nodes[hit.node].material;
+        const bool need_uv = mi >= 0 && (S.materials[mi].diffuse.map >= 0 || S.materials[mi].specular.map >= 0);
+        Attr a;
+        hit_attrs(S, o, d, hit.t, hit.node, hit.prim, need_uv, a);
+        shade_entry(S, R, F, f, o, a, hit.node, bounce, gi, code, skey, so);
+        ray_owner = f;
+        atomicAdd(&cnt->n_shade, 1u);
+    } else if (active) {
+        if (kind == RK_CAMERA) {
+            // background.Sample((i/W, j/H, 0)), Main.cpp:166-167
+            int pi, pj;
+            pixel_of(P, P.q0 + owner / (uint32_t)P.spp, pi, pj);
+            st3(samples, owner, tc_sample(S, S.background, v3((float)pi / S.cam.width, (float)pj / S.cam.height, 0.0f)));
+        } else if (kind == RK_GI) {
+            V3 mult = ld3i(F.gi_mult, owner);
+            V3 outc = v3(0, 0, 0);
+            if (is_hit) {
+                outc = outc + v3(0, 0, 0) * mult; // |z| <= Bias: indirect stays black (MtlBlinn.cpp:398-406)
+            } else if (d.x == d.y && d.x == 0) {
+                outc = outc + v3(1.0f, 0.0f, 1.0f); // MtlBlinn.cpp:411-415
+            } else {
+                V3 env = sample_environment(S, S.environment, d) * mult;
+                if (!(isnan_f(env.x) || isnan_f(env.y) || isnan_f(env.z))) outc = outc + env;
+            }
+            if (isnan_f(outc.x)) outc = v3(1.0f, 0.0f, 1.0f);
+            else outc = clamp_white(outc);
+            st3(F.gi, owner, outc);
+        } else if (kind == RK_REFR_IN) {
+            if (!is_hit) {
+                st3(F.refr, owner, v3(1.0f, 0.0f, 1.0f)); // RefractionRecusive returns NANPurple (MtlBlinn.cpp:517)
+            } else {
+                // back face: HandleRayWhenRefractionRayOut (MtlBlinn.cpp:543-589)
+                Attr a;
+                hit_attrs(S, o, d, hit.t, hit.node, hit.prim, false, a);
+                const bhrt_material &m = S.materials[(F.info[owner] >> 20) & 0xfffu];
+                const float refrGloss = m.glossiness > 50 ? m.glossiness : 0.f;
+                V3 vN = a.N;
+                V3 vV = -d;
+                float cosPhi1 = dot(vV, -vN);
+                float sinPhi1 = sqrtf(1 - cosPhi1 * cosPhi1);
+                float sinPhi2 = m.ior * sinPhi1;
+                if (sinPhi2 <= 1) {
+                    float cosPhi2 = sqrtf(1 - sinPhi2 * sinPhi2);
+                    V3 vTn = vN * cosPhi2;
+                    V3 vNxV = cross(vN, vV);
+                    V3 vTp = normalized(cross(vN, vNxV)) * sinPhi2;
+                    V3 vT = vTn + vTp;
+                    V3 vT_sampled = normalized(vT);
+                    if (refrGloss > 0) {
+                        DRng g;
+                        g.key = bhrt_section_key(F.skey[owner], F.code[owner], BHRT_SEC_REFRACTION);
+                        g.ctr = ctr;
+                        float dotSign = 0;
+                        int guard = 0;
+                        while (dotSign <= 0 && guard++ < BHRT_MAXLOOP) {
+                            float theta = 0;
+                            vT_sampled = sample_along_light_direction(g, vT, refrGloss, theta);
+                            dotSign = dot(vT_sampled, vN);
+                        }
+                        ctr = g.ctr;
+                    }
+                    so.has_refr = true;
+                    so.rd = normalized(vT_sampled);
+                    so.ro = a.p + vN * BHRT_BIAS;
+                    so.rmeta = make_meta(RK_REFR_OUT, BHRT_HIT_FRONT, bounce);
+                    so.rctr = ctr;
+                } else if (bounce <= 0) {
+                    st3(F.refr, owner, v3(0, 0, 0)); // MtlBlinn.cpp:496-500
+                } else {
+                    V3 vR = ((-2 * cosPhi1) * vN - vV); // total internal reflection, MtlBlinn.cpp:580-587,502-503
+                    so.has_refr = true;
+                    so.rd = vR;
+                    so.ro = a.p - vN * BHRT_BIAS;
+                    so.rmeta = make_meta(RK_REFR_IN, BHRT_HIT_FRONT_AND_BACK, bounce - 1);
+                    so.rctr = ctr;
+                }
+            }
+        } else { // RK_REFR_OUT miss: refraction * environment (MtlBlinn.cpp:535-539)
+            st3(F.refr, owner, clamp_white(ld3i(F.refr_color, owner) * sample_environment(S, S.environment, d)));
+        }
+    }
+
+    // ---- convergent pushes
+    const uint32_t r0 = wave_alloc(&cnt->n_next, so.has_refr);
+    const uint32_t r1 = wave_alloc(&cnt->n_next, so.has_gi);
+    const uint32_t s0 = wave_alloc(&cnt->n_shadow, so.has_shadow);
+    if (so.has_refr) {
+        if (r0 < R.cap_rays) put_ray(qout, r0, so.ro, so.rd, ray_owner, so.rmeta, so.rctr);
+        else atomicOr(&cnt->overflow, 2u);
+    }
+    if (so.has_gi) {
+        if (r1 < R.cap_rays) put_ray(qout, r1, so.go, so.gd, ray_owner, make_meta(RK_GI, BHRT_HIT_FRONT, 0), 0);
+        else atomicOr(&cnt->overflow, 2u);
+    }
+    if (so.has_shadow) {
+        if (s0 < R.cap_shadow) {
+            qs.ox[s0] = so.so.x; qs.oy[s0] = so.so.y; qs.oz[s0] = so.so.z; qs.dx[s0] = so.sd.x; qs.dy[s0] = so.sd.y; qs.dz[s0] = so.sd.z;
+            qs.tmax[s0] = so.stmax; qs.frame[s0] = ray_owner;
+        } else atomicOr(&cnt->overflow, 4u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fold frames [f0, f1) (all created in one wave step) into their parents / the sample buffer.
+__global__ void __launch_bounds__(kBlock) k_combine(DevScene S, Frames F, uint32_t f0, uint32_t f1, float *samples)
+{
+    const uint32_t f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= f1) return;
+    const uint32_t info = F.info[f];
+    const uint32_t how = info & 7u, dmode = (info >> 3) & 7u, li = (info >> 8) & 0xffu, flags = (info >> 16) & 0xfu;
+    V3 out;
+    if (flags & FF_CONST) out = ld3i(F.refr, f);
+    else {
+        // Shade(), MtlBlinn.cpp:117-137
+        out = v3(0, 0, 0);
+        out = out + ld3i(F.refr, f);
+        bool done = out.x >= 1 && out.y >= 1 && out.z >= 1;
+        if (!done) {
+            out = out + ld3i(F.gi, f);
+            done = out.x >= 1 && out.y >= 1 && out.z >= 1;
+        }
+        if (!done) {
+            // PathTracing_DiffuseNSpecular, MtlBlinn.cpp:304-351
+            V3 dc = v3(0, 0, 0);
+            if (dmode != DM_NONE) {
+                const bhrt_light &l = S.lights[li];
+                V3 I = ld3(l.intensity), irrad;
+                const float vis = F.vis[f];
+                if (dmode == DM_AMBIENT) irrad = I;
+                else if (dmode == DM_DIRECT) irrad = vis * I;                       // lights.h:50
+                else if (dmode == DM_POINT) irrad = (vis * I) / F.rr[f];            // PointLight.cpp:14-17
+                else irrad = v3(1, 1, 1) * BHRT_BIGFLOAT;                           // PointLight.cpp:12
+                dc = dc + irrad * ld3i(F.brdf, f);
+            }
+            dc = dc + ld3i(F.caustic, f);
+            dc = clamp_white(dc);
+            if (isnan_f(dc.x)) dc = v3(0, 0, 0);
+            out = out + dc;
+            done = out.x >= 1 && out.y >= 1 && out.z >= 1;
+            if (!done && isnan_f(out.x)) out = v3(1.0f, 0.0f, 1.0f);
+        }
+    }
+    const uint32_t parent = F.parent[f];
+    if (how == FH_ROOT) st3(samples, parent, out);
+    else if (how == FH_GI) { // MtlBlinn.cpp:406,427-432
+        V3 oc = v3(0, 0, 0) + out * ld3i(F.mult, f);
+        if (isnan_f(oc.x)) oc = v3(1.0f, 0.0f, 1.0f);
+        else oc = clamp_white(oc);
+        st3(F.gi, parent, oc);
+    } else if (how == FH_REFR_FRONT) st3(F.refr, parent, clamp_white(out)); // MtlBlinn.cpp:509-511
+    else st3(F.refr, parent, clamp_white(ld3i(F.mult, f) * out));           // MtlBlinn.cpp:533,539
+}
+
+// in-order sample average (Main.cpp:150-170), gamma (Main.cpp:220-226), Color24 (cyColor.h:271-272)
+__global__ void __launch_bounds__(kBlock) k_resolve(PassInfo P, const float *samples, float *radiance, uint8_t *rgb8)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= P.n_pixels) return;
+    int i, j;
+    if (!pixel_of(P, P.q0 + q, i, j)) return;
+    V3 sum = v3(0, 0, 0);
+    for (int s = 0; s < P.spp; s++) sum = sum + ld3i(samples, q * (uint32_t)P.spp + (uint32_t)s);
+    V3 out = sum / (float)P.spp;
+    const size_t pix = (size_t)j * P.W + i;
+    if (radiance) st3(radiance, (uint32_t)pix, out);
+    if (rgb8) {
+        if (P.gamma) {
+            const float inv = 1 / 2.2f;
+            out = v3(dm::powf_(out.x, inv), dm::powf_(out.y, inv), dm::powf_(out.z, inv));
+        }
+        int r = int(out.x * 255 + 0.5f), g = int(out.y * 255 + 0.5f), b = int(out.z * 255 + 0.5f);
+        rgb8[pix * 3] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        rgb8[pix * 3 + 1] = (uint8_t)(g < 0 ? 0 : (g > 255 ? 255 : g));
+        rgb8[pix * 3 + 2] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
+    }
+}
+
+__global__ void k_copy_samples(PassInfo P, const float *samples, int x0, int y0, int x1, int y1, float *out)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= P.n_pixels) return;
+    int i, j;
+    if (!pixel_of(P, P.q0 + q, i, j)) return;
+    if (i < x0 || i >= x1 || j < y0 || j >= y1) return;
+    const size_t pix = (size_t)(j - y0) * (x1 - x0) + (i - x0);
+    for (int s = 0; s < P.spp; s++)
+        for (int c = 0; c < 3; c++) out[(pix * P.spp + s) * 3 + c] = samples[((size_t)q * P.spp + s) * 3 + c];
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct DeviceState {
+    int device = -1;
+    uint8_t *d_blob = nullptr;
+    int32_t *d_chain = nullptr;
+    DevScene S;
+    // wavefront workspace
+    uint32_t cap_samples = 0, cap_rays = 0, cap_frames = 0;
+    float *d_rayf[2] = {nullptr, nullptr};     // 6 * cap_rays floats each
+    uint32_t *d_rayu[2] = {nullptr, nullptr};  // 3 * cap_rays
+    float *d_hitf = nullptr;                   // cap_rays
+    int32_t *d_hiti = nullptr;                 // 3 * cap_rays
+    float *d_shf = nullptr;                    // 7 * cap_rays
+    uint32_t *d_shu = nullptr;                 // cap_rays
+    uint32_t *d_fu = nullptr;                  // 4 * cap_frames
+    uint64_t *d_fcode = nullptr;               // cap_frames
+    float *d_ff = nullptr;                     // (3*7 + 2) * cap_frames
+    float *d_samples = nullptr;                // 3 * cap_samples
+    Counters *d_cnt = nullptr;
+    Counters *h_cnt = nullptr; // pinned
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    // scratch for the public trace API
+    float *d_api_f = nullptr;
+    int32_t *d_api_i = nullptr;
+    size_t api_cap = 0;
+};
+
+void DestroyDeviceState(DeviceState *d)
+{
+    if (!d) return;
+    if (d->device >= 0) (void)hipSetDevice(d->device);
+    auto fr = [](void *p) { if (p) (void)hipFree(p); };
+    fr(d->d_blob); fr(d->d_chain);
+    for (int k = 0; k < 2; k++) { fr(d->d_rayf[k]); fr(d->d_rayu[k]); }
+    fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_cnt);
+    fr(d->d_api_f); fr(d->d_api_i);
+    if (d->h_cnt) (void)hipHostFree(d->h_cnt);
+    for (int k = 0; k < 2; k++) if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+}
+
+static RayQueue MakeRayQueue(float *f, uint32_t *u, size_t cap)
+{
+    RayQueue q;
+    q.ox = f; q.oy = f + cap; q.oz = f + 2 * cap; q.dx = f + 3 * cap; q.dy = f + 4 * cap; q.dz = f + 5 * cap;
+    q.frame = u; q.meta = u ? u + cap : nullptr; q.rng_ctr = u ? u + 2 * cap : nullptr;
+    return q;
+}
+
+static int EnsureUploaded(bhrt_scene *scene)
+{
+    if (!scene) { SetError("null scene"); return BHRT_ERR_ARG; }
+    if (scene->dev) { HIP_CHECK(hipSetDevice(scene->dev->device)); return BHRT_OK; }
+    return bhrt_scene_upload(scene, 0);
+}
+
+static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, uint32_t frames_per_sample)
+{
+    if (D->cap_samples >= cap_samples && D->cap_frames >= cap_samples * frames_per_sample) return BHRT_OK;
+    auto fr = [](void *p) { if (p) (void)hipFree(p); };
+    for (int k = 0; k < 2; k++) { fr(D->d_rayf[k]); fr(D->d_rayu[k]); D->d_rayf[k] = nullptr; D->d_rayu[k] = nullptr; }
+    fr(D->d_hitf); fr(D->d_hiti); fr(D->d_shf); fr(D->d_shu); fr(D->d_fu); fr(D->d_fcode); fr(D->d_ff); fr(D->d_samples);
+    D->d_hitf = nullptr; D->d_hiti = nullptr; D->d_shf = nullptr; D->d_shu = nullptr; D->d_fu = nullptr; D->d_fcode = nullptr; D->d_ff = nullptr; D->d_samples = nullptr;
+    D->cap_samples = 0;
+    const size_t cr = (size_t)cap_samples * 2, cf = (size_t)cap_samples * frames_per_sample;
+    for (int k = 0; k < 2; k++) {
+        HIP_CHECK(hipMalloc(&D->d_rayf[k], cr * 6 * sizeof(float)));
+        HIP_CHECK(hipMalloc(&D->d_rayu[k], cr * 3 * sizeof(uint32_t)));
+    }
+    HIP_CHECK(hipMalloc(&D->d_hitf, cr * sizeof(float)));
+    HIP_CHECK(hipMalloc(&D->d_hiti, cr * 3 * sizeof(int32_t)));
+    HIP_CHECK(hipMalloc(&D->d_shf, cr * 7 * sizeof(float)));
+    HIP_CHECK(hipMalloc(&D->d_shu, cr * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&D->d_fu, cf * 4 * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&D->d_fcode, cf * sizeof(uint64_t)));
+    HIP_CHECK(hipMalloc(&D->d_ff, cf * 23 * sizeof(float)));
+    HIP_CHECK(hipMalloc(&D->d_samples, (size_t)cap_samples * 3 * sizeof(float)));
+    D->cap_samples = cap_samples; D->cap_rays = (uint32_t)cr; D->cap_frames = (uint32_t)cf;
+    return BHRT_OK;
+}
+
+static Frames MakeFrames(DeviceState *D)
+{
+    Frames F;
+    const size_t c = D->cap_frames;
+    F.parent = D->d_fu; F.info = D->d_fu + c; F.info2 = D->d_fu + 2 * c; F.skey = D->d_fu + 3 * c;
+    F.code = D->d_fcode;
+    float *p = D->d_ff;
+    F.mult = p; p += 3 * c; F.refr = p; p += 3 * c; F.gi = p; p += 3 * c; F.gi_mult = p; p += 3 * c;
+    F.brdf = p; p += 3 * c; F.refr_color = p; p += 3 * c; F.caustic = p; p += 3 * c;
+    F.rr = p; p += c; F.vis = p;
+    return F;
+}
+
+struct Timer {
+    DeviceState *D;
+    double *acc;
+    Timer(DeviceState *d, double *a) : D(d), acc(a) { (void)hipEventRecord(D->ev[0], D->stream); }
+    void Stop()
+    {
+        (void)hipEventRecord(D->ev[1], D->stream);
+        (void)hipEventSynchronize(D->ev[1]);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, D->ev[0], D->ev[1]);
+        *acc += ms * 1e-3;
+    }
+};
+
+// Renders owned pixels [q_begin, q_end) of this rank; samples_out (device) receives the per-sample buffer
+// of the region when requested (parity tests).
+static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, float *d_radiance, bhrt_stats *st, float *d_region_samples, int x0,
+                       int y0, int x1, int y1)
+{
+    DeviceState *D = scene->dev;
+    const bhrt_flat_header *H = scene->flat.hdr();
+    const int W = H->camera.width, Hh = H->camera.height;
+    const int tile = o.tile_size > 0 ? o.tile_size : 32;
+    const int world = o.world_size > 0 ? o.world_size : 1;
+    if (o.rank < 0 || o.rank >= world) { SetError("rank outside world_size"); return BHRT_ERR_ARG; }
+    if (o.spp <= 0 || o.spp > 65535) { SetError("spp must be in 1..65535"); return BHRT_ERR_ARG; }
+    if (o.internal_bounces < 0 || o.internal_bounces > 255 || o.gi_bounces < -1 || o.gi_bounces > 60) { SetError("bounce counts out of range"); return BHRT_ERR_ARG; }
+    if (H->n_materials > 4095 || H->n_lights > 255) { SetError("too many materials/lights for the frame record"); return BHRT_ERR_UNSUPPORTED; }
+    PassInfo P;
+    P.W = W; P.H = Hh; P.tile = tile; P.tiles_x = (W + tile - 1) / tile; P.tiles_y = (Hh + tile - 1) / tile;
+    P.rank = o.rank; P.world = world; P.spp = o.spp; P.seed = o.seed; P.jitter = o.jitter; P.gamma = o.gamma;
+    const uint32_t n_tiles = (uint32_t)(P.tiles_x * P.tiles_y);
+    const uint32_t owned_tiles = n_tiles > (uint32_t)o.rank ? (n_tiles - (uint32_t)o.rank + (uint32_t)world - 1) / (uint32_t)world : 0;
+    const uint64_t owned_pixels = (uint64_t)owned_tiles * tile * tile;
+
+    uint32_t pass_samples = o.samples_per_pass > 0 ? (uint32_t)o.samples_per_pass : (1u << 21);
+    if (pass_samples < (uint32_t)o.spp) pass_samples = (uint32_t)o.spp;
+    const uint32_t frames_per_sample = 12;
+    RenderParams R;
+    R.internal_bounces = o.internal_bounces; R.gi_bounces = o.gi_bounces; R.photon = o.photon_map;
+    auto wall0 = std::chrono::steady_clock::now();
+
+    uint64_t q = 0;
+    uint32_t pass_limit = 0; // samples actually put in flight per pass (<= buffer capacity)
+    while (q < owned_pixels) {
+        int rc = EnsureWorkspace(D, pass_samples, frames_per_sample);
+        if (rc) return rc;
+        R.cap_rays = D->cap_rays; R.cap_shadow = D->cap_rays; R.cap_frames = D->cap_frames;
+        if (pass_limit == 0 || pass_limit > D->cap_samples) pass_limit = D->cap_samples;
+        const uint32_t px_per_pass = pass_limit / (uint32_t)o.spp;
+        const uint32_t npx = (uint32_t)std::min<uint64_t>(px_per_pass, owned_pixels - q);
+        P.q0 = (uint32_t)q; P.n_pixels = npx;
+        RayQueue Q[2] = {MakeRayQueue(D->d_rayf[0], D->d_rayu[0], D->cap_rays), MakeRayQueue(D->d_rayf[1], D->d_rayu[1], D->cap_rays)};
+        HitBuf HB; HB.t = D->d_hitf; HB.node = D->d_hiti; HB.prim = D->d_hiti + D->cap_rays; HB.front = D->d_hiti + 2 * (size_t)D->cap_rays;
+        ShadowQueue SQ; { float *p = D->d_shf; const size_t c = D->cap_rays; SQ.ox = p; SQ.oy = p + c; SQ.oz = p + 2 * c; SQ.dx = p + 3 * c; SQ.dy = p + 4 * c; SQ.dz = p + 5 * c; SQ.tmax = p + 6 * c; SQ.frame = D->d_shu; }
+        Frames F = MakeFrames(D);
+        HIP_CHECK(hipMemsetAsync(D->d_cnt, 0, sizeof(Counters), D->stream));
+        HIP_CHECK(hipMemsetAsync(D->d_samples, 0, (size_t)npx * o.spp * 3 * sizeof(float), D->stream));
+        const uint32_t total = npx * (uint32_t)o.spp;
+        {
+            Timer t(D, &st->seconds_other);
+            hipLaunchKernelGGL(k_camera_rays, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, P, Q[0], D->d_cnt);
+            t.Stop();
+        }
+        HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, D->stream));
+        HIP_CHECK(hipStreamSynchronize(D->stream));
+        uint32_t n_cur = D->h_cnt->n_next;
+        st->camera_samples += n_cur;
+        int cur = 0;
+        std::vector<uint32_t> frame_marks = {0};
+        bool overflow = false;
+        while (n_cur > 0) {
+            {
+                Timer t(D, &st->seconds_trace_closest);
+                hipLaunchKernelGGL(k_trace_closest, dim3((n_cur + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, Q[cur], n_cur, 0, HB);
+                t.Stop();
+            }
+            st->closest_rays += n_cur; st->launches_trace_closest++;
+            // reset the per-step queue counters (frames keep counting across steps)
+            HIP_CHECK(hipMemsetAsync(&D->d_cnt->n_next, 0, 2 * sizeof(uint32_t), D->stream));
+            {
+                Timer t(D, &st->seconds_shade);
+                hipLaunchKernelGGL(k_shade, dim3((n_cur + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt);
+                t.Stop();
+            }
+            HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, D->stream));
+            HIP_CHECK(hipStreamSynchronize(D->stream));
+            if (D->h_cnt->overflow) { overflow = true; break; }
+            const uint32_t n_sh = D->h_cnt->n_shadow;
+            if (n_sh) {
+                Timer t(D, &st->seconds_trace_shadow);
+                hipLaunchKernelGGL(k_trace_shadow, dim3((n_sh + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, SQ, n_sh, F.vis);
+                t.Stop();
+                st->shadow_rays += n_sh; st->launches_trace_shadow++;
+            }
+            frame_marks.push_back(D->h_cnt->n_frames);
+            n_cur = D->h_cnt->n_next;
+            cur ^= 1;
+            st->wave_iterations++;
+        }
+        if (overflow) {
+            // a capacity was exceeded: redo this pass with half the pixels in the same buffers
+            // (results do not depend on the pass size: every sample has its own RNG key)
+            if (pass_limit <= (uint32_t)o.spp) { SetError("wavefront buffers overflow even with one pixel per pass"); return BHRT_ERR_OVERFLOW; }
+            pass_limit = std::max<uint32_t>((uint32_t)o.spp, pass_limit / 2);
+            continue;
+        }
+        st->shade_calls += D->h_cnt->n_shade;
+        {
+            Timer t(D, &st->seconds_other);
+            for (size_t k = frame_marks.size(); k-- > 1;) {
+                const uint32_t f0 = frame_marks[k - 1], f1 = frame_marks[k];
+                if (f1 > f0) hipLaunchKernelGGL(k_combine, dim3((f1 - f0 + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, F, f0, f1, D->d_samples);
+            }
+            hipLaunchKernelGGL(k_resolve, dim3((npx + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, P, D->d_samples, d_radiance, d_rgb8);
+            if (d_region_samples)
+                hipLaunchKernelGGL(k_copy_samples, dim3((npx + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, P, D->d_samples, x0, y0, x1, y1, d_region_samples);
+            t.Stop();
+        }
+        HIP_CHECK(hipGetLastError());
+        st->passes++;
+        q += npx;
+    }
+    HIP_CHECK(hipStreamSynchronize(D->stream));
+    st->seconds_total += std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+    return BHRT_OK;
+}
+
+} // namespace bhrt
+
+using namespace bhrt;
+
+extern "C" {
+
+int bhrt_device_count(int *n)
+{
+    if (!n) { SetError("null argument"); return BHRT_ERR_ARG; }
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; SetError(std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); return BHRT_ERR_NO_DEVICE; }
+    *n = c;
+    return BHRT_OK;
+}
+
+int bhrt_scene_upload(bhrt_scene *scene, int device)
+{
+    if (!scene) { SetError("null scene"); return BHRT_ERR_ARG; }
+    if (scene->dev && scene->dev->device == device) { HIP_CHECK(hipSetDevice(device)); return BHRT_OK; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { SetError("no HIP device available (this path has no CPU fallback)"); return BHRT_ERR_NO_DEVICE; }
+    if (device < 0 || device >= count) { SetError("device index out of range"); return BHRT_ERR_ARG; }
+    if (scene->max_bvh_depth > 64) { SetError("BVH deeper than 64 levels: the stackless trail holds 64"); return BHRT_ERR_UNSUPPORTED; }
+    if (scene->dev) { DestroyDeviceState(scene->dev); scene->dev = nullptr; }
+    HIP_CHECK(hipSetDevice(device));
+    DeviceState *D = new DeviceState;
+    D->device = device;
+    scene->dev = D;
+    const std::vector<uint8_t> &blob = scene->flat.blob;
+    const bhrt_flat_header *H = scene->flat.hdr();
+    HIP_CHECK(hipStreamCreate(&D->stream));
+    HIP_CHECK(hipEventCreate(&D->ev[0]));
+    HIP_CHECK(hipEventCreate(&D->ev[1]));
+    HIP_CHECK(hipMalloc(&D->d_blob, blob.size()));
+    HIP_CHECK(hipMemcpy(D->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    // ancestor chains (depth-1 ancestor first, the node itself last)
+    std::vector<int32_t> chain((size_t)std::max<uint32_t>(H->n_nodes, 1) * BHRT_MAX_NODE_DEPTH, 0);
+    const bhrt_node *nodes = (const bhrt_node *)(blob.data() + H->off_nodes);
+    for (uint32_t n = 0; n < H->n_nodes; n++) {
+        int k = nodes[n].depth - 1, c = (int)n;
+        while (c >= 0 && k >= 0) { chain[(size_t)n * BHRT_MAX_NODE_DEPTH + k] = c; c = nodes[c].parent; k--; }
+    }
+    HIP_CHECK(hipMalloc(&D->d_chain, chain.size() * sizeof(int32_t)));
+    HIP_CHECK(hipMemcpy(D->d_chain, chain.data(), chain.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMalloc(&D->d_cnt, sizeof(Counters)));
+    HIP_CHECK(hipHostMalloc(&D->h_cnt, sizeof(Counters)));
+    DevScene &S = D->S;
+    S.blob = D->d_blob;
+    S.nodes = (const bhrt_node *)(D->d_blob + H->off_nodes);
+    S.meshes = (const bhrt_mesh *)(D->d_blob + H->off_meshes);
+    S.materials = (const bhrt_material *)(D->d_blob + H->off_materials);
+    S.lights = (const bhrt_light *)(D->d_blob + H->off_lights);
+    S.texmaps = (const bhrt_texmap *)(D->d_blob + H->off_texmaps);
+    S.textures = (const bhrt_texture *)(D->d_blob + H->off_textures);
+    S.chain = D->d_chain;
+    S.n_nodes = (int32_t)H->n_nodes; S.n_lights = (int32_t)H->n_lights;
+    S.all_light_intensity = H->all_light_intensity;
+    S.cam = H->camera; S.background = H->background; S.environment = H->environment;
+    S.tapx[0] = S.tapy[0] = 0;
+    for (int i = 1; i < 32; i++) { // scene.h:322-329 with the deterministic sin/cos (host and device agree bit for bit)
+        auto halton = [](int index, int base) { float r = 0, f = 1.0f / (float)base; for (int k = index; k > 0; k /= base) { r += f * (k % base); f /= (float)base; } return r; };
+        float x = halton(i, 2), y = halton(i, 3);
+        float r = sqrtf(x) * 0.5f;
+        S.tapx[i] = r * dm::sinf_(y * (float)M_PI * 2);
+        S.tapy[i] = r * dm::cosf_(y * (float)M_PI * 2);
+    }
+    return BHRT_OK;
+}
+
+static int EnsureApiScratch(DeviceState *D, size_t n)
+{
+    if (D->api_cap >= n) return BHRT_OK;
+    if (D->d_api_f) (void)hipFree(D->d_api_f);
+    if (D->d_api_i) (void)hipFree(D->d_api_i);
+    D->d_api_f = nullptr; D->d_api_i = nullptr; D->api_cap = 0;
+    HIP_CHECK(hipMalloc(&D->d_api_f, n * 9 * sizeof(float)));
+    HIP_CHECK(hipMalloc(&D->d_api_i, n * 3 * sizeof(int32_t)));
+    D->api_cap = n;
+    return BHRT_OK;
+}
+
+int bhrt_trace_closest_dev(bhrt_scene *scene, const float *d_rays_soa, int hit_side, size_t n, bhrt_hits d_out, void *stream)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    if (!d_rays_soa || !d_out.t || !d_out.node || !d_out.prim || !d_out.front) { SetError("null buffer"); return BHRT_ERR_ARG; }
+    if (hit_side < 1 || hit_side > 3) { SetError("hit_side must be 1, 2 or 3"); return BHRT_ERR_ARG; }
+    if (n == 0) return BHRT_OK;
+    if (n > 0x7fffffffu) { SetError("too many rays for one call"); return BHRT_ERR_ARG; }
+    RayQueue q = MakeRayQueue(const_cast<float *>(d_rays_soa), nullptr, n);
+    HitBuf h; h.t = d_out.t; h.node = d_out.node; h.prim = d_out.prim; h.front = d_out.front;
+    hipStream_t s = stream ? (hipStream_t)stream : scene->dev->stream;
+    hipLaunchKernelGGL(k_trace_closest, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, q, (uint32_t)n, hit_side, h);
+    HIP_CHECK(hipGetLastError());
+    if (!stream) HIP_CHECK(hipStreamSynchronize(s));
+    return BHRT_OK;
+}
+
+int bhrt_trace_closest_host(bhrt_scene *scene, const float *rays_soa, int hit_side, size_t n, bhrt_hits out)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    if (n == 0) return BHRT_OK;
+    if (!rays_soa || !out.t || !out.node || !out.prim || !out.front) { SetError("null buffer"); return BHRT_ERR_ARG; }
+    DeviceState *D = scene->dev;
+    rc = EnsureApiScratch(D, n);
+    if (rc) return rc;
+    HIP_CHECK(hipMemcpy(D->d_api_f, rays_soa, n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    bhrt_hits d; d.t = D->d_api_f + 6 * n; d.node = D->d_api_i; d.prim = D->d_api_i + n; d.front = D->d_api_i + 2 * n;
+    rc = bhrt_trace_closest_dev(scene, D->d_api_f, hit_side, n, d, nullptr);
+    if (rc) return rc;
+    HIP_CHECK(hipMemcpy(out.t, d.t, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out.node, d.node, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out.prim, d.prim, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out.front, d.front, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return BHRT_OK;
+}
+
+int bhrt_trace_shadow_dev(bhrt_scene *scene, const float *d_rays_soa, const float *d_tmax, size_t n, float *d_vis, void *stream)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    if (!d_rays_soa || !d_tmax || !d_vis) { SetError("null buffer"); return BHRT_ERR_ARG; }
+    if (n == 0) return BHRT_OK;
+    if (n > 0x7fffffffu) { SetError("too many rays for one call"); return BHRT_ERR_ARG; }
+    ShadowQueue q;
+    float *f = const_cast<float *>(d_rays_soa);
+    q.ox = f; q.oy = f + n; q.oz = f + 2 * n; q.dx = f + 3 * n; q.dy = f + 4 * n; q.dz = f + 5 * n;
+    q.tmax = const_cast<float *>(d_tmax); q.frame = nullptr;
+    hipStream_t s = stream ? (hipStream_t)stream : scene->dev->stream;
+    hipLaunchKernelGGL(k_trace_shadow, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, q, (uint32_t)n, d_vis);
+    HIP_CHECK(hipGetLastError());
+    if (!stream) HIP_CHECK(hipStreamSynchronize(s));
+    return BHRT_OK;
+}
+
+int bhrt_trace_shadow_host(bhrt_scene *scene, const float *rays_soa, const float *tmax, size_t n, float *vis)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    if (n == 0) return BHRT_OK;
+    if (!rays_soa || !tmax || !vis) { SetError("null buffer"); return BHRT_ERR_ARG; }
+    DeviceState *D = scene->dev;
+    rc = EnsureApiScratch(D, n);
+    if (rc) return rc;
+    HIP_CHECK(hipMemcpy(D->d_api_f, rays_soa, n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(D->d_api_f + 6 * n, tmax, n * sizeof(float), hipMemcpyHostToDevice));
+    rc = bhrt_trace_shadow_dev(scene, D->d_api_f, D->d_api_f + 6 * n, n, D->d_api_f + 7 * n, nullptr);
+    if (rc) return rc;
+    HIP_CHECK(hipMemcpy(vis, D->d_api_f + 7 * n, n * sizeof(float), hipMemcpyDeviceToHost));
+    return BHRT_OK;
+}
+
+int bhrt_render_dev(bhrt_scene *scene, const bhrt_opts *opts, uint8_t *d_rgb8, float *d_radiance, bhrt_stats *stats, void *stream)
+{
+    (void)stream; // the render pipeline synchronises its own stream per wave step
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    if (!opts) { SetError("null opts"); return BHRT_ERR_ARG; }
+    if (opts->photon_map) { SetError("photon-map gather is not available in this build"); return BHRT_ERR_UNSUPPORTED; }
+    bhrt_stats local;
+    memset(&local, 0, sizeof local);
+    rc = RenderRange(scene, *opts, d_rgb8, d_radiance, &local, nullptr, 0, 0, 0, 0);
+    if (stats) *stats = local;
+    return rc;
+}
+
+int bhrt_render(bhrt_scene *scene, const bhrt_opts *opts, uint8_t *rgb8, float *radiance, bhrt_stats *stats)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    const bhrt_flat_header *H = scene->flat.hdr();
+    const size_t npix = (size_t)H->camera.width * H->camera.height;
+    uint8_t *d_rgb = nullptr;
+    float *d_rad = nullptr;
+    if (rgb8) { HIP_CHECK(hipMalloc(&d_rgb, npix * 3)); HIP_CHECK(hipMemcpy(d_rgb, rgb8, npix * 3, hipMemcpyHostToDevice)); }
+    if (radiance) { HIP_CHECK(hipMalloc(&d_rad, npix * 3 * sizeof(float))); HIP_CHECK(hipMemcpy(d_rad, radiance, npix * 3 * sizeof(float), hipMemcpyHostToDevice)); }
+    rc = bhrt_render_dev(scene, opts, d_rgb, d_rad, stats, nullptr);
+    if (rc == BHRT_OK) {
+        if (rgb8) HIP_CHECK(hipMemcpy(rgb8, d_rgb, npix * 3, hipMemcpyDeviceToHost));
+        if (radiance) HIP_CHECK(hipMemcpy(radiance, d_rad, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    if (d_rgb) (void)hipFree(d_rgb);
+    if (d_rad) (void)hipFree(d_rad);
+    return rc;
+}
+
+int bhrt_render_samples(bhrt_scene *scene, const bhrt_opts *opts, int x0, int y0, int x1, int y1, float *samples, bhrt_stats *stats)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    if (!opts || !samples) { SetError("null argument"); return BHRT_ERR_ARG; }
+    const bhrt_flat_header *H = scene->flat.hdr();
+    if (x0 < 0 || y0 < 0 || x1 > H->camera.width || y1 > H->camera.height || x0 >= x1 || y0 >= y1) { SetError("bad region"); return BHRT_ERR_ARG; }
+    if (opts->photon_map) { SetError("photon-map gather is not available in this build"); return BHRT_ERR_UNSUPPORTED; }
+    const size_t nfl = (size_t)(x1 - x0) * (y1 - y0) * opts->spp * 3;
+    float *d_s = nullptr;
+    HIP_CHECK(hipMalloc(&d_s, nfl * sizeof(float)));
+    HIP_CHECK(hipMemset(d_s, 0, nfl * sizeof(float)));
+    bhrt_stats local;
+    memset(&local, 0, sizeof local);
+    rc = RenderRange(scene, *opts, nullptr, nullptr, &local, d_s, x0, y0, x1, y1);
+    if (rc == BHRT_OK) HIP_CHECK(hipMemcpy(samples, d_s, nfl * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(d_s);
+    if (stats) *stats = local;
+    return rc;
+}
+
+int bhrt_photon_build(bhrt_scene *, const bhrt_opts *, uint32_t, uint32_t *) { SetError("photon map: not available in this build"); return BHRT_ERR_UNSUPPORTED; }
+int bhrt_photon_gather_host(bhrt_scene *, const float *, const float *, size_t, float, float *, float *) { SetError("photon map: not available in this build"); return BHRT_ERR_UNSUPPORTED; }
+int bhrt_photon_export(const bhrt_scene *, const char *) { SetError("photon map: not available in this build"); return BHRT_ERR_UNSUPPORTED; }
+
+} // extern "C"

@@ -664,7 +664,7 @@ template <class M> struct Shader {
         Vec3 rndVec(0, 0, 1);
         int guard = 0;
         while (V.Cross(rndVec).IsZero() && guard++ < O_MAXLOOP) {
-            float a = rng.Rnd01(), b = rng.Rnd01(), c = rng.Rnd01(); // constructor arguments: evaluated right-to-left by g++? see note
+            float c = rng.Rnd01(), b = rng.Rnd01(), a = rng.Rnd01(); // g++ evaluates the constructor arguments right to left (checked against oracle/_ref)
             rndVec = Vec3(a, b, c);
         }
         return rndVec;

@@ -1,0 +1,128 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so) — the CHECKER.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+
+RNG_SEQUENTIAL, RNG_KEYED = 0, 1
+MATH_LIBM, MATH_DEVICE = 0, 1
+HIT_FLOATS = 16
+
+
+class OracleOpts(C.Structure):
+    _fields_ = [("spp", C.c_int32), ("gi_bounces", C.c_int32), ("internal_bounces", C.c_int32), ("seed", C.c_uint32),
+                ("rng_mode", C.c_int32), ("math_mode", C.c_int32), ("jitter", C.c_int32),
+                ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32),
+                ("threads", C.c_int32), ("photon_gather", C.c_int32)]
+
+
+class OracleStats(C.Structure):
+    _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("shade_calls", C.c_uint64),
+                ("samples", C.c_uint64), ("seconds", C.c_double)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.oracle_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f"oracle error {rc}: {lib().oracle_last_error().decode()}")
+
+
+def trace_closest(blob: bytes, origins, dirs, hit_side=1):
+    rays = np.ascontiguousarray(np.concatenate([origins, dirs], axis=1), np.float32)
+    n = rays.shape[0]
+    node = np.empty(n, np.int32)
+    face = np.empty(n, np.int32)
+    front = np.empty(n, np.int32)
+    attrs = np.empty((n, HIT_FLOATS), np.float32)
+    _check(lib().oracle_trace_closest(C.c_char_p(blob), _p(rays), int(hit_side), C.c_size_t(n), _p(node), _p(face),
+                                      _p(front), _p(attrs)))
+    return {"node": node, "prim": face, "front": front, "t": attrs[:, 0].copy(), "attrs": attrs}
+
+
+def trace_shadow(blob: bytes, origins, dirs, tmax):
+    rays = np.ascontiguousarray(np.concatenate([origins, dirs], axis=1), np.float32)
+    n = rays.shape[0]
+    tm = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, np.float32), (n,)), np.float32)
+    vis = np.empty(n, np.float32)
+    _check(lib().oracle_trace_shadow(C.c_char_p(blob), _p(rays), _p(tm), C.c_size_t(n), _p(vis)))
+    return vis
+
+
+def render(blob: bytes, width, height, spp, gi=3, bounces=16, seed=0, rng=RNG_KEYED, math=MATH_DEVICE, jitter=1,
+           region=None, threads=8, want_samples=True):
+    x0, y0, x1, y1 = region if region else (0, 0, width, height)
+    o = OracleOpts(spp, gi, bounces, seed, rng, math, jitter, x0, y0, x1, y1, threads, 0)
+    npx = (x1 - x0) * (y1 - y0)
+    samples = np.zeros((npx, spp, 3), np.float32) if want_samples else None
+    rad = np.zeros((npx, 3), np.float32)
+    rgb = np.zeros((npx, 3), np.uint8)
+    st = OracleStats()
+    _check(lib().oracle_render(C.c_char_p(blob), C.byref(o), _p(samples) if want_samples else None, _p(rad), _p(rgb),
+                               C.byref(st)))
+    return {"samples": samples, "radiance": rad.reshape(y1 - y0, x1 - x0, 3), "rgb8": rgb.reshape(y1 - y0, x1 - x0, 3),
+            "stats": st}
+
+
+def bvh_build(v, f, max_per_leaf=4):
+    v = np.ascontiguousarray(v, np.float32)
+    f = np.ascontiguousarray(f, np.uint32)
+    nf = f.shape[0]
+    cap = 2 * nf + 2
+    nodes = np.zeros((cap, 8), np.uint32)
+    elems = np.zeros(nf, np.uint32)
+    n = lib().oracle_bvh_build(_p(v), _p(f), nf, max_per_leaf, _p(nodes), C.c_size_t(cap), _p(elems))
+    if n < 0:
+        raise RuntimeError(lib().oracle_last_error().decode())
+    return nodes[:n].copy(), elems
+
+
+def math_eval(fn: int, mode: int, a, b=None):
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.empty_like(a)
+    bb = np.ascontiguousarray(b, np.float32) if b is not None else None
+    _check(lib().oracle_math_eval(fn, mode, _p(a), _p(bb) if bb is not None else None, C.c_size_t(a.size), _p(out)))
+    return out
+
+
+def primary_rays(flat_view):
+    """The reference's un-jittered camera rays (Main.cpp:145,153) for every pixel, row-major j*W+i."""
+    c = flat_view.header.camera
+    W, H = c.width, c.height
+    tl = np.array(list(c.top_left), np.float32)
+    dx = np.array(list(c.dd_x), np.float32)
+    dy = np.array(list(c.dd_y), np.float32)
+    pos = np.array(list(c.pos), np.float32)
+    ii, jj = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    pc = (tl[None, None, :] + ii[..., None] * dx[None, None, :]) - jj[..., None] * dy[None, None, :]
+    d = (pc - pos[None, None, :]).reshape(-1, 3).astype(np.float32)
+    o = np.broadcast_to(pos, d.shape).astype(np.float32).copy()
+    return o, d
