@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s + wall-clock per frame of the HIP render path on BASELINE.json's config.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c1]
+
+A "step" = one full frame of the workload through the hot path (camera rays -> wavefront
+trace/shade steps -> combine -> resolve [-> RCCL framebuffer gather when N > 1]).
+N = 1 default workload = BASELINE.json configs[1]: tests/scenes/c2_glass.xml, 1920x1080, 16 spp,
+GI depth 3 (4 levels = "reflection/refraction depth 4"), internal bounces 16, keyed RNG seed 0.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); interleaved 32x32 tiles
+(tile t -> rank t mod N), spp scaled to 16*N so per-GPU work is fixed (weak
+scaling), then one all_gather of the packed tile buffers over xGMI inside the timed region.
+The scene is resident in HBM before the timed region; outputs stay in HBM.
+
+Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (scene, width, height, spp, gi)
+    "c1": ("tests/scenes/c1_sphere_plane.xml", 640, 480, 1, -1),
+    "c2": ("tests/scenes/c2_glass.xml", 1920, 1080, 16, 3),
+    "c3": ("tests/scenes/c3_mesh.xml", 1920, 1080, 64, 3),
+}
+BYTES_PER_CLOSEST_RAY = 56  # 32 B ray read + 24 B hit write
+BYTES_PER_SHADOW_RAY = 36   # 32 B read + 4 B visibility write
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def ensure_assets():
+    mesh = os.path.join(ROOT, "tests/scenes/gen/mesh_224.obj")
+    if not os.path.exists(mesh):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import gen_mesh
+        gen_mesh.generate(mesh, 224)
+
+
+def cpu_baseline(scene_path, spp, gi):
+    """Reference CPU path on a bounded sample of the same workload, on this box's host cores.
+
+    kind "reference": the reference itself (oracle/_ref/ref_harness, compiled from /root/reference in the dev
+    container) run as one single-threaded process per row band (its RNG is a process-global);
+    kind "port": the oracle (sequential RNG + libm = the mode pinned bit-for-bit to the reference), OpenMP.
+    Ray counts come from the oracle (identical control flow)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    import bhraytracer_amd as B
+    sc = B.Scene(scene_path)
+    blob = sc.flat_bytes()
+    W, H = sc.width, sc.height
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    rows = max(cores, (H // 8) // cores * cores)  # about 1/8 of the frame, a multiple of the core count
+    y0 = (H - rows) // 2
+    region = (0, y0, W, y0 + rows)
+    t0 = time.time()
+    ro = O.render(blob, W, H, spp, gi=gi, rng=O.RNG_SEQUENTIAL, math=O.MATH_LIBM, region=region, threads=cores,
+                  want_samples=False)
+    port_s = time.time() - t0
+    rays = ro["stats"].closest_rays + ro["stats"].shadow_rays
+    sample = f"rows {y0}..{y0 + rows} of {W}x{H} ({rows * W} pixels x {spp} spp, {rays} rays)"
+    out = {"value": rays / port_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample}
+    harness = os.path.join(ROOT, "oracle/_ref/ref_harness")
+    if os.path.exists(harness):
+        try:
+            band = rows // cores
+            tmp = tempfile.mkdtemp(prefix="bhrt_ref_")
+            t0 = time.time()
+            procs = []
+            for k in range(cores):
+                a, b = y0 + k * band, y0 + (k + 1) * band
+                cmd = [harness, os.path.abspath(scene_path), os.path.join(tmp, f"b{k}"), "--spp", str(spp), "--gi", str(gi),
+                       "--region", "0", str(a), str(W), str(b), "render"]
+                procs.append(subprocess.Popen(cmd, cwd=os.path.dirname(os.path.abspath(scene_path)),
+                                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+            ok = all(p.wait() == 0 for p in procs)
+            ref_s = time.time() - t0
+            if ok:
+                out = {"value": rays / ref_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference",
+                       "sample": sample + f"; {cores} single-threaded reference processes (incl. scene load)",
+                       "port_value": rays / port_s / 1e6}
+            subprocess.run(["rm", "-rf", tmp])
+        except Exception:
+            pass
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    N = max(1, world)
+
+    import numpy as np
+    import torch
+    import bhraytracer_amd as B
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if N > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    if rank == 0:
+        ensure_assets()
+    if N > 1:
+        dist.barrier()
+    scene_rel, W, H, spp1, gi = WORKLOADS[args.workload]
+    scene_path = os.path.join(ROOT, scene_rel)
+    sc = B.Scene(scene_path)
+    assert (sc.width, sc.height) == (W, H), "scene size differs from the workload table"
+    sc.upload(local_rank)
+    spp = spp1 * N  # weak scaling: per-GPU sample count is fixed
+    tile = 32
+    opts = B.default_opts(spp=spp, gi_bounces=gi, internal_bounces=16, seed=0, rank=rank, world_size=N, tile_size=tile)
+
+    d_rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    d_rad = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    tiles_x, tiles_y = (W + tile - 1) // tile, (H + tile - 1) // tile
+    n_tiles = tiles_x * tiles_y
+    per_rank = (n_tiles + N - 1) // N
+
+    def gather_framebuffer():
+        """RCCL all_gather of each rank's packed tiles, then de-interleave (tile t = k*N + r)."""
+        padded = torch.zeros((tiles_y * tile, tiles_x * tile, 3), dtype=torch.float32, device=dev)
+        padded[:H, :W] = d_rad
+        t = padded.view(tiles_y, tile, tiles_x, tile, 3).permute(0, 2, 1, 3, 4).reshape(n_tiles, tile, tile, 3)
+        mine = torch.zeros((per_rank, tile, tile, 3), dtype=torch.float32, device=dev)
+        own = t[rank::N]
+        mine[: own.shape[0]] = own
+        allb = torch.empty((N, per_rank, tile, tile, 3), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(allb, mine)
+        full = allb.permute(1, 0, 2, 3, 4).reshape(per_rank * N, tile, tile, 3)[:n_tiles]
+        img = full.view(tiles_y, tiles_x, tile, tile, 3).permute(0, 2, 1, 3, 4).reshape(tiles_y * tile, tiles_x * tile, 3)
+        return img[:H, :W]
+
+    def step():
+        st = sc.render_dev(opts, d_rgb.data_ptr(), d_rad.data_ptr())
+        if N > 1:
+            gather_framebuffer()
+        return st
+
+    def sync():
+        if N > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    agg = None
+    for _ in range(args.steps):
+        st = step()
+        d = st.as_dict()
+        agg = d if agg is None else {k: agg[k] + d[k] for k in d}
+    sync()
+    elapsed = time.perf_counter() - t0
+    rays_local = agg["closest_rays"] + agg["shadow_rays"]
+    if N > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        rr = torch.tensor([rays_local, agg["closest_rays"], agg["camera_samples"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        rays_total, closest_total, samples_total = (float(x) for x in rr.tolist())
+    else:
+        rays_total, closest_total, samples_total = float(rays_local), float(agg["closest_rays"]), float(agg["camera_samples"])
+
+    if rank == 0:
+        # roofline of the dominant kernel on this rank (HIP-event time measured inside the library on its stream)
+        k_times = {"k_trace_closest": agg["seconds_trace_closest"], "k_trace_shadow": agg["seconds_trace_shadow"],
+                   "k_shade": agg["seconds_shade"], "other": agg["seconds_other"]}
+        launches = max(1, agg["launches_trace_closest"])
+        avg_launch_s = agg["seconds_trace_closest"] / launches
+        rays_per_launch = agg["closest_rays"] / launches
+        achieved = BYTES_PER_CLOSEST_RAY * rays_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get(args.workload, {}).get("k_trace_closest_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (closest-hit + any-hit rays per second), with wall-clock per frame",
+            "value": rays_total / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{os.path.basename(scene_rel)} {W}x{H}, {spp} spp ({spp1} per GPU), GI depth {gi}, "
+                                   f"internal bounces 16, keyed RNG seed 0, {tile}x{tile} interleaved tiles over {N} GPU(s)",
+                       "rays_per_frame": rays_total / args.steps, "camera_samples_per_frame": samples_total / args.steps,
+                       "framebuffer_gather": "rccl all_gather (float radiance tiles)" if N > 1 else "none"},
+            "kernel_seconds": k_times,
+            "wave_steps_per_frame": agg["wave_iterations"] / args.steps,
+            "roofline": {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "avg_launch_ms": avg_launch_s * 1e3, "rays_per_launch": rays_per_launch,
+                         "bytes_per_ray": BYTES_PER_CLOSEST_RAY,
+                         "note": "scene is cache-resident; traversal is latency/divergence bound (DESIGN.md)"},
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_path, spp1, gi)
+        print(json.dumps(out), flush=True)
+    if N > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
