@@ -33,6 +33,7 @@ WORKLOADS = {
 }
 BYTES_PER_CLOSEST_RAY = 56  # 32 B ray read + 24 B hit write
 BYTES_PER_SHADOW_RAY = 36   # 32 B read + 4 B visibility write
+BYTES_PER_SHADE_VERTEX = 92  # 24 hit + 32 ray read, 12 radiance, 24 next-ray writes
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -57,7 +58,7 @@ def cpu_baseline(scene_path, spp, gi):
     sc = B.Scene(scene_path)
     blob = sc.flat_bytes()
     W, H = sc.width, sc.height
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    cores = max(1, min(os.cpu_count() or 1, 16))  # the GPU box's CPU share for one GPU
     rows = max(cores, (H // 8) // cores * cores)  # about 1/8 of the frame, a multiple of the core count
     y0 = (H - rows) // 2
     region = (0, y0, W, y0 + rows)
@@ -112,6 +113,7 @@ def main():
     import numpy as np
     import torch
     import bhraytracer_amd as B
+    import bhraytracer_amd.dist as BD
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
@@ -137,28 +139,12 @@ def main():
 
     d_rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
     d_rad = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    tiles_x, tiles_y = (W + tile - 1) // tile, (H + tile - 1) // tile
-    n_tiles = tiles_x * tiles_y
-    per_rank = (n_tiles + N - 1) // N
-
-    def gather_framebuffer():
-        """RCCL all_gather of each rank's packed tiles, then de-interleave (tile t = k*N + r)."""
-        padded = torch.zeros((tiles_y * tile, tiles_x * tile, 3), dtype=torch.float32, device=dev)
-        padded[:H, :W] = d_rad
-        t = padded.view(tiles_y, tile, tiles_x, tile, 3).permute(0, 2, 1, 3, 4).reshape(n_tiles, tile, tile, 3)
-        mine = torch.zeros((per_rank, tile, tile, 3), dtype=torch.float32, device=dev)
-        own = t[rank::N]
-        mine[: own.shape[0]] = own
-        allb = torch.empty((N, per_rank, tile, tile, 3), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(allb, mine)
-        full = allb.permute(1, 0, 2, 3, 4).reshape(per_rank * N, tile, tile, 3)[:n_tiles]
-        img = full.view(tiles_y, tiles_x, tile, tile, 3).permute(0, 2, 1, 3, 4).reshape(tiles_y * tile, tiles_x * tile, 3)
-        return img[:H, :W]
 
     def step():
         st = sc.render_dev(opts, d_rgb.data_ptr(), d_rad.data_ptr())
         if N > 1:
-            gather_framebuffer()
+            BD.gather_framebuffer(d_rad, tile, rank, N)  # RCCL all_gather of the float radiance tiles
+            BD.gather_framebuffer(d_rgb, tile, rank, N)  # and of the RGB8 tiles
         return st
 
     def sync():
@@ -189,20 +175,28 @@ def main():
         rays_total, closest_total, samples_total = float(rays_local), float(agg["closest_rays"]), float(agg["camera_samples"])
 
     if rank == 0:
-        # roofline of the dominant kernel on this rank (HIP-event time measured inside the library on its stream)
+        # roofline of the dominant kernel on this rank (HIP-event time measured inside the library on its stream).
+        # Algorithmic bytes per unit are SURVEY.md 8(d)'s: closest-hit ray 56 B, any-hit ray 36 B, shade vertex 92 B.
         k_times = {"k_trace_closest": agg["seconds_trace_closest"], "k_trace_shadow": agg["seconds_trace_shadow"],
                    "k_shade": agg["seconds_shade"], "other": agg["seconds_other"]}
-        launches = max(1, agg["launches_trace_closest"])
-        avg_launch_s = agg["seconds_trace_closest"] / launches
-        rays_per_launch = agg["closest_rays"] / launches
-        achieved = BYTES_PER_CLOSEST_RAY * rays_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        units = {"k_trace_closest": (agg["closest_rays"], BYTES_PER_CLOSEST_RAY, agg["launches_trace_closest"]),
+                 "k_trace_shadow": (agg["shadow_rays"], BYTES_PER_SHADOW_RAY, agg["launches_trace_shadow"]),
+                 "k_shade": (agg["closest_rays"], BYTES_PER_SHADE_VERTEX, agg["launches_trace_closest"])}
+        dom = max(units, key=lambda k: k_times[k])
+        n_units, bpu, launches = units[dom]
+        launches = max(1, launches)
+        avg_launch_s = k_times[dom] / launches
+        units_per_launch = n_units / launches
+        achieved = bpu * units_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get(args.workload, {}).get("k_trace_closest_bytes_per_launch")
+                traffic = json.load(open(prof)).get(args.workload, {}).get(dom + "_bytes_per_launch")
             except Exception:
                 traffic = None
+        per_kernel = {k: {"seconds": k_times[k], "units": units[k][0], "bytes_per_unit": units[k][1], "launches": units[k][2],
+                          "GBps": (units[k][0] * units[k][1] / k_times[k] / 1e9) if k_times[k] > 0 else 0.0} for k in units}
         out = {
             "metric": "Mrays/s (closest-hit + any-hit rays per second), with wall-clock per frame",
             "value": rays_total / elapsed / 1e6,
@@ -217,14 +211,15 @@ def main():
             "config": {"workload": f"{os.path.basename(scene_rel)} {W}x{H}, {spp} spp ({spp1} per GPU), GI depth {gi}, "
                                    f"internal bounces 16, keyed RNG seed 0, {tile}x{tile} interleaved tiles over {N} GPU(s)",
                        "rays_per_frame": rays_total / args.steps, "camera_samples_per_frame": samples_total / args.steps,
-                       "framebuffer_gather": "rccl all_gather (float radiance tiles)" if N > 1 else "none"},
+                       "framebuffer_gather": "rccl all_gather (float radiance + rgb8 tiles)" if N > 1 else "none"},
             "kernel_seconds": k_times,
+            "kernels": per_kernel,
             "wave_steps_per_frame": agg["wave_iterations"] / args.steps,
-            "roofline": {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "avg_launch_ms": avg_launch_s * 1e3, "rays_per_launch": rays_per_launch,
-                         "bytes_per_ray": BYTES_PER_CLOSEST_RAY,
-                         "note": "scene is cache-resident; traversal is latency/divergence bound (DESIGN.md)"},
+                         "avg_launch_ms": avg_launch_s * 1e3, "units_per_launch": units_per_launch,
+                         "bytes_per_unit": bpu,
+                         "note": "scene is cache-resident; traversal/shading are latency- and ALU-bound, not HBM-bound (DESIGN.md)"},
         }
         if N == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_path, spp1, gi)

@@ -145,13 +145,23 @@ BHRT_DM double asin_pos_d(double x)
     double t = x;
     if (big) t = sqrt_d((1.0 - x) * 0.5);
     double z = t * t;
-    // asin t = sum c_n t^(2n+1), c_n = (2n)! / (4^n (n!)^2 (2n+1)); z <= 0.25, 20 terms -> < 1e-14
-    double c = 1.0, sum = 1.0, zp = 1.0;
-    for (int n = 1; n <= 20; n++) {
-        c = c * (double)(2 * n - 1) / (double)(2 * n);
-        zp = zp * z;
-        sum = sum + c * zp / (double)(2 * n + 1);
-    }
+    // asin t = t * sum c_n z^n, c_n = (2n)! / (4^n (n!)^2 (2n+1)) as correctly rounded literals;
+    // z <= 0.25 and 15 terms leave < 1e-11 relative, Horner form, no run-time division
+    double sum = 0.005153309682319905;
+    sum = 0.005740037670841924 + z * sum;
+    sum = 0.006447210311889649 + z * sum;
+    sum = 0.0073125258735988454 + z * sum;
+    sum = 0.008390335809616815 + z * sum;
+    sum = 0.009761609529194078 + z * sum;
+    sum = 0.011551800896139705 + z * sum;
+    sum = 0.01396484375 + z * sum;
+    sum = 0.017352764423076924 + z * sum;
+    sum = 0.022372159090909092 + z * sum;
+    sum = 0.030381944444444444 + z * sum;
+    sum = 0.044642857142857144 + z * sum;
+    sum = 0.075 + z * sum;
+    sum = 0.16666666666666666 + z * sum;
+    sum = 1.0 + z * sum;
     double a = t * sum;
     return big ? pio2 - 2.0 * a : a;
 }

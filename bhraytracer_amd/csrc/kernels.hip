@@ -674,9 +674,9 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
     const uint32_t owned_tiles = n_tiles > (uint32_t)o.rank ? (n_tiles - (uint32_t)o.rank + (uint32_t)world - 1) / (uint32_t)world : 0;
     const uint64_t owned_pixels = (uint64_t)owned_tiles * tile * tile;
 
-    uint32_t pass_samples = o.samples_per_pass > 0 ? (uint32_t)o.samples_per_pass : (1u << 21);
+    uint32_t pass_samples = o.samples_per_pass > 0 ? (uint32_t)o.samples_per_pass : (1u << 24); // sized for 288 GB of HBM: few, large passes
     if (pass_samples < (uint32_t)o.spp) pass_samples = (uint32_t)o.spp;
-    const uint32_t frames_per_sample = 12;
+    const uint32_t frames_per_sample = 6; // Shade() frames per camera sample; an overflow halves the pass and retries
     RenderParams R;
     R.internal_bounces = o.internal_bounces; R.gi_bounces = o.gi_bounces; R.photon = o.photon_map;
     auto wall0 = std::chrono::steady_clock::now();

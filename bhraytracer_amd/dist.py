@@ -1,0 +1,59 @@
+"""Tile partition + framebuffer gather for the multi-GPU path.
+
+The image is cut into square tiles; tile t (row-major) belongs to rank t mod N — interleaved,
+because cost is spatially uneven (glass / mesh pixels cost far more than background).  Every rank
+renders only its tiles (bhrt_opts.rank/world_size/tile_size), then ONE collective moves each
+rank's packed tiles to everybody: an all_gather over RCCL/xGMI (backend "nccl" on ROCm; "gloo" in
+the CPU tests).  No other collective exists on this path: samples are keyed by global (pixel,
+sample), so the image does not depend on N.
+
+torch is plumbing here (device buffers + torch.distributed); the render itself is libbhrt.so.
+"""
+import torch
+
+
+def tile_grid(width: int, height: int, tile: int):
+    tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
+    return tx, ty, tx * ty
+
+
+def owned_mask(width: int, height: int, tile: int, rank: int, world: int) -> torch.Tensor:
+    """(H, W) bool: pixels whose tile belongs to `rank` (same rule as pixel_of() in kernels.hip)."""
+    tx, ty, _ = tile_grid(width, height, tile)
+    jj = torch.arange(height).unsqueeze(1) // tile
+    ii = torch.arange(width).unsqueeze(0) // tile
+    return ((jj * tx + ii) % world) == rank
+
+
+def pack_tiles(img: torch.Tensor, tile: int, rank: int, world: int) -> torch.Tensor:
+    """(H, W, C) image -> (tiles_per_rank, tile, tile, C) buffer holding this rank's tiles (zero padded)."""
+    H, W, Cc = img.shape
+    tx, ty, n_tiles = tile_grid(W, H, tile)
+    per_rank = (n_tiles + world - 1) // world
+    padded = torch.zeros((ty * tile, tx * tile, Cc), dtype=img.dtype, device=img.device)
+    padded[:H, :W] = img
+    t = padded.view(ty, tile, tx, tile, Cc).permute(0, 2, 1, 3, 4).reshape(n_tiles, tile, tile, Cc)
+    mine = torch.zeros((per_rank, tile, tile, Cc), dtype=img.dtype, device=img.device)
+    own = t[rank::world]
+    mine[: own.shape[0]] = own
+    return mine
+
+
+def unpack_tiles(allb: torch.Tensor, width: int, height: int, tile: int) -> torch.Tensor:
+    """(world, tiles_per_rank, tile, tile, C) gathered buffer -> (H, W, C) image (tile t = k*world + r)."""
+    world, per_rank, _, _, Cc = allb.shape
+    tx, ty, n_tiles = tile_grid(width, height, tile)
+    full = allb.permute(1, 0, 2, 3, 4).reshape(per_rank * world, tile, tile, Cc)[:n_tiles]
+    img = full.reshape(ty, tx, tile, tile, Cc).permute(0, 2, 1, 3, 4).reshape(ty * tile, tx * tile, Cc)
+    return img[:height, :width]
+
+
+def gather_framebuffer(img: torch.Tensor, tile: int, rank: int, world: int, group=None) -> torch.Tensor:
+    """All ranks end up with the complete image. One all_gather, (W*H*C*itemsize)/world bytes per rank."""
+    import torch.distributed as dist
+    if world == 1:
+        return img
+    mine = pack_tiles(img, tile, rank, world).contiguous()
+    allb = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=img.dtype, device=img.device)
+    dist.all_gather_into_tensor(allb, mine, group=group)  # rank r's block lands at rows [r*per_rank, (r+1)*per_rank)
+    return unpack_tiles(allb.view((world,) + tuple(mine.shape)), img.shape[1], img.shape[0], tile)

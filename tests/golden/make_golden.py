@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REFERENCE ITSELF (oracle/_ref/ref_harness = the unmodified
+reference compiled in place from /root/reference by oracle/Makefile).  Runs only in the development
+container; the resulting fixtures are data (inputs + expected outputs) and are committed.
+
+The reference has no tests or golden vectors of its own, so these are the pins:
+  <scene>_primary   hit table of the un-jittered camera rays (Main.cpp:145,153 -> recursive(), Main.cpp:389):
+                    node index, front flag, and the bits of z / p / N / uv for every 4th (8th for wide images) pixel,
+                    plus SHA-256 digests of the complete tables
+  <scene>_rays      seeded pseudo-random secondary rays with hitSide FRONT / BACK / FRONT_AND_BACK
+  <scene>_shadow    GenLight::Shadow (GenLight.cpp:10) for rays from primary hit points towards the light
+  <scene>_render    per-sample radiance of MtlBlinn::Shade (MtlBlinn.cpp:89) over a pixel region, rand()
+                    interposed by the sequential stream of include/bhrt_rng.h, plus the gamma/Color24 bytes
+"""
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SCENES = os.path.join(ROOT, "tests", "scenes")
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+
+# scene file, render region, spp, gi
+CASES = {
+    "c1_sphere_plane": ("c1_sphere_plane.xml", (270, 180, 334, 228), 4, 3),
+    "c2_glass_small": ("c2_glass_small.xml", (120, 110, 184, 158), 4, 3),
+    "c3_mesh_small": ("c3_mesh_small.xml", (110, 70, 174, 118), 4, 3),
+    "c4_textured": ("c4_textured.xml", (100, 90, 164, 138), 4, 2),
+}
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def run(scene, prefix, *args):
+    subprocess.run([HARNESS, scene, prefix, *map(str, args)], cwd=SCENES, check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+
+
+def secondary_rays(seed, n, lo, hi):
+    rng = np.random.RandomState(seed)
+    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    return o, d
+
+
+def main():
+    if not os.path.exists(HARNESS):
+        sys.exit("oracle/_ref/ref_harness missing: run `make -C oracle ref` in the development container")
+    tmp = tempfile.mkdtemp(prefix="bhrt_golden_")
+    for name, (xml, region, spp, gi) in CASES.items():
+        pre = os.path.join(tmp, name)
+        run(xml, pre, "dump", "primary")
+        cam = np.fromfile(pre + ".camera_f32", np.float32)
+        W, H = int(cam[11]), int(cam[12])
+        pi = np.fromfile(pre + ".primary_i32", np.int32).reshape(H, W, 2)
+        pf = np.fromfile(pre + ".primary_f32", np.float32).reshape(H, W, 16)
+        step = 8 if W > 400 else 4
+        sub = (slice(None, None, step), slice(None, None, step))
+        out = {
+            "width": W, "height": H, "primary_step": step,
+            "primary_node_sha": sha(pi[..., 0]), "primary_z_sha": sha(pf[..., 0]),
+            "primary_pN_sha": sha(pf[..., 1:7][pi[..., 0] >= 0]),
+            "primary_node": pi[..., 0][sub].astype(np.int16), "primary_front": pi[..., 1][sub].astype(np.int8),
+            "primary_attrs": pf[sub][..., :9].copy(),  # z, p, N, u, v (uvw.z of a sphere hit is uninitialised in the reference)
+            "primary_duvw": pf[sub][..., 10:16].copy(),
+        }
+        # secondary rays, all three hit sides
+        o, d = secondary_rays(1234, 3000, -12.0, 12.0)
+        o[:, 2] = np.abs(o[:, 2]) * 0.8 + 0.05
+        for side in (1, 2, 3):
+            rays = np.concatenate([o, d, np.full((len(o), 1), side, np.float32)], axis=1).astype(np.float32)
+            rays.tofile(pre + ".rays_in")
+            run(xml, pre, "--rays", pre + ".rays_in", "rays")
+            ri = np.fromfile(pre + ".rays_i32", np.int32).reshape(-1, 2)
+            rf = np.fromfile(pre + ".rays_f32", np.float32).reshape(-1, 16)
+            out[f"rays_node_{side}"] = ri[:, 0].astype(np.int16)
+            out[f"rays_front_{side}"] = ri[:, 1].astype(np.int8)
+            out[f"rays_z_{side}"] = rf[:, 0].copy()
+        out["rays_o"], out["rays_d"] = o, d
+        # shadow rays from every 4th primary hit towards the brightest point light
+        lights = np.fromfile(pre + ".lights_f32", np.float32)[:-1].reshape(-1, 8)
+        pl = lights[lights[:, 0] == 2]
+        hitmask = out["primary_node"] >= 0
+        P = out["primary_attrs"][..., 1:4][hitmask]
+        if len(pl) and len(P):
+            L = pl[-1, 4:7]
+            sd = (L[None, :] - P).astype(np.float32)
+            sr = np.concatenate([P, sd, np.ones((len(P), 1), np.float32)], axis=1).astype(np.float32)
+            sr.tofile(pre + ".shadow_in")
+            run(xml, pre, "--shadow", pre + ".shadow_in", "shadow")
+            out["shadow_o"], out["shadow_d"] = P.astype(np.float32), sd
+            out["shadow_vis"] = np.fromfile(pre + ".shadow_f32", np.float32).astype(np.int8)
+        # integrator
+        x0, y0, x1, y1 = region
+        run(xml, pre, "--spp", spp, "--gi", gi, "--region", x0, y0, x1, y1, "render")
+        npx = (x1 - x0) * (y1 - y0)
+        out["render_region"] = np.array(region, np.int32)
+        out["render_spp"], out["render_gi"] = spp, gi
+        out["render_samples"] = np.fromfile(pre + ".samples_f32", np.float32).reshape(npx, spp, 3)
+        out["render_radiance"] = np.fromfile(pre + ".radiance_f32", np.float32).reshape(npx, 3)
+        out["render_rgb8"] = np.fromfile(pre + ".rgb8", np.uint8).reshape(npx, 3)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {int((pi[..., 0] >= 0).sum())}/{W * H} primary hits")
+    subprocess.run(["rm", "-rf", tmp])
+
+
+if __name__ == "__main__":
+    main()

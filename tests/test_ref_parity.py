@@ -1,0 +1,91 @@
+"""Live comparison of the oracle with the compiled reference (oracle/_ref/ref_harness).  Only runs where
+/root/reference exists (the development container); the committed fixtures in tests/golden carry the same
+pins to the GPU box."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REFERENCE, REF_HARNESS, ROOT, SCENES, same_bits
+
+pytestmark = pytest.mark.skipif(not (os.path.isdir(REFERENCE) and os.path.exists(REF_HARNESS)),
+                                reason="needs /root/reference and oracle/_ref (development container only)")
+
+
+def run_ref(scene, prefix, *args, cwd):
+    subprocess.run([REF_HARNESS, scene, prefix, *map(str, args)], cwd=cwd, check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+
+
+def test_scene_dump_matches_front_end(B, tmp_path):
+    # transforms, camera frame, light order, meshes and the BVH: bit for bit
+    sc = B.Scene(os.path.join(SCENES, "c4_textured.xml"))
+    fv = sc.flat_view()
+    pre = str(tmp_path / "d")
+    run_ref("c4_textured.xml", pre, "dump", cwd=SCENES)
+    nf = np.fromfile(pre + ".nodes_f32", np.uint32).reshape(-1, 21)
+    mine = np.array([list(n.xf.tm) + list(n.xf.pos) + list(n.xf.itm) for n in fv.nodes], np.float32).view(np.uint32)
+    assert np.array_equal(nf, mine)
+    ni = np.fromfile(pre + ".nodes_i32", np.int32).reshape(-1, 5)
+    assert np.array_equal(ni, np.array([[n.parent, n.depth, n.obj_type, n.mesh, n.material] for n in fv.nodes], np.int32))
+    m = fv.mesh_arrays(0)
+    assert np.array_equal(np.fromfile(pre + ".mesh0.bvh_u32", np.uint32), m["bvh_data"])
+    assert np.array_equal(np.fromfile(pre + ".mesh0.bvh_f32", np.uint32).reshape(-1, 6)[1:], m["bvh_bounds"].view(np.uint32)[1:])
+    assert np.array_equal(np.fromfile(pre + ".mesh0.elems_u32", np.uint32), m["elems"])
+    assert np.array_equal(np.fromfile(pre + ".mesh0.vn_f32", np.uint32), m["vn"].view(np.uint32).ravel())
+    lf = np.fromfile(pre + ".lights_f32", np.float32)
+    assert [int(t) for t in lf[:-1].reshape(-1, 8)[:, 0]] == [l.type for l in fv.lights]     # CalculateLightsIntensity sort
+    assert lf[-1] == np.float32(fv.header.all_light_intensity)
+
+
+SHIPPED = ["proj12_backfaceTest", "proj3", "proj13", "proj7", "proj10", "proj2"]
+
+
+@pytest.mark.parametrize("name", SHIPPED)
+def test_integrator_on_shipped_scenes(name, B, O, tmp_path):
+    """MtlBlinn::Shade through GI depth 3 on the reference's own scene files (meshes absent -> null objects)."""
+    xml = os.path.join("Resource", "Data", name + ".xml")
+    region = (330, 260, 430, 330)
+    spp = 2
+    pre = str(tmp_path / name)
+    run_ref(xml, pre, "--spp", spp, "--gi", 3, "--region", *region, "render", cwd=REFERENCE)
+    cwd = os.getcwd()
+    os.chdir(REFERENCE)
+    try:
+        sc = B.Scene(xml)
+    finally:
+        os.chdir(cwd)
+    r = O.render(sc.flat_bytes(), sc.width, sc.height, spp, gi=3, rng=O.RNG_SEQUENTIAL, math=O.MATH_LIBM, region=region, threads=4)
+    npx = (region[2] - region[0]) * (region[3] - region[1])
+    assert same_bits(r["samples"], np.fromfile(pre + ".samples_f32", np.float32).reshape(npx, spp, 3))
+    assert np.array_equal(r["rgb8"].reshape(-1, 3), np.fromfile(pre + ".rgb8", np.uint8).reshape(npx, 3))
+
+
+def test_large_mesh_primary_hits(B, O, tmp_path):
+    """BASELINE config 3 geometry (100,352 triangles): BVH node-for-node and every primary hit bit-exact."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_mesh
+    mesh = os.path.join(SCENES, "gen", "mesh_224.obj")
+    if not os.path.exists(mesh):
+        gen_mesh.generate(mesh, 224)
+    txt = open(os.path.join(SCENES, "c3_mesh.xml")).read().replace('<width value="1920"/>', '<width value="480"/>').replace('<height value="1080"/>', '<height value="270"/>')
+    xml = os.path.join(SCENES, "_tmp_c3_480.xml")
+    open(xml, "w").write(txt)
+    try:
+        pre = str(tmp_path / "c3")
+        run_ref("_tmp_c3_480.xml", pre, "dump", "primary", cwd=SCENES)
+        sc = B.Scene(xml)
+    finally:
+        os.remove(xml)
+    m = sc.flat_view().mesh_arrays(0)
+    assert m["f"].shape[0] == 100352
+    assert np.array_equal(np.fromfile(pre + ".mesh0.bvh_u32", np.uint32), m["bvh_data"])
+    o, d = O.primary_rays(sc.flat_view())
+    r = O.trace_closest(sc.flat_bytes(), o, d, 1)
+    ri = np.fromfile(pre + ".primary_i32", np.int32).reshape(-1, 2)
+    rf = np.fromfile(pre + ".primary_f32", np.float32).reshape(-1, 16)
+    assert np.array_equal(ri[:, 0], r["node"])
+    hit = r["node"] >= 0
+    assert same_bits(r["attrs"][hit][:, :9], rf[hit][:, :9])
