@@ -29,7 +29,8 @@ enum : uint32_t {
     RK_CAMERA = 0,   // Main.cpp:153-158      frame = sample slot
     RK_GI = 1,       // MtlBlinn.cpp:392-396  frame = shading frame that asked
     RK_REFR_IN = 2,  // MtlBlinn.cpp:478-483
-    RK_REFR_OUT = 3  // MtlBlinn.cpp:524-526
+    RK_REFR_OUT = 3, // MtlBlinn.cpp:524-526
+    RK_DEAD = 15     // padding slot (pixel of an edge tile outside the image): never traced or shaded
 };
 // how a frame's result reaches its parent
 enum : uint32_t { FH_ROOT = 0, FH_GI = 1, FH_REFR_FRONT = 2, FH_REFR_OUT = 3 };
@@ -76,7 +77,7 @@ struct Counters {
     uint32_t n_shadow;  // rays pushed to the shadow queue
     uint32_t n_frames;  // frames allocated so far in this pass
     uint32_t overflow;  // set when a capacity was exceeded
-    uint32_t n_shade;   // Shade() evaluations (stats)
+    uint32_t n_shade;   // unused (Shade() evaluations == n_frames)
     uint32_t pad[3];
 };
 

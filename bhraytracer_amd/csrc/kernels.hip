@@ -65,21 +65,48 @@ __device__ inline bool pixel_of(const PassInfo &P, uint32_t q, int &i, int &j)
     return ty < (uint32_t)P.tiles_y && i < P.W && j < P.H;
 }
 
-// wave64 compaction: ballot + prefix popcount, one atomic per wave (convergent call sites only)
-__device__ inline uint32_t wave_alloc(uint32_t *counter, bool pred)
+// Queue compaction: wave64 ballot + prefix popcount inside each wave, wave totals combined through LDS,
+// ONE atomic per workgroup and queue.  (One atomic per wave was the bottleneck of the first version: a
+// single word takes ~88 atomics/us on MI355X, and a 16 M-lane launch has 262 k waves.)
+// All threads of the block must call it (convergent call sites only).  kShadeBlock threads per block.
+constexpr int kShadeBlock = 1024;
+constexpr int kShadeWaves = kShadeBlock / 64;
+
+struct BlockAllocLds {
+    uint32_t total[3][kShadeWaves];
+    uint32_t base[3][kShadeWaves];
+};
+
+// per-lane request of `cnt` (0..2) slots from up to three counters at once; returns this lane's first slot
+__device__ inline void block_alloc3(BlockAllocLds &L, uint32_t *c0, uint32_t n0a, uint32_t n0b, uint32_t *c1, uint32_t n1, uint32_t *c2, uint32_t n2,
+                                    uint32_t &s0a, uint32_t &s0b, uint32_t &s1, uint32_t &s2)
 {
-    const uint64_t mask = __ballot(pred);
-    uint32_t idx = 0xffffffffu;
-    if (mask) {
-        const uint32_t lane = __lane_id();
-        const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        const int leader = __ffsll((long long)mask) - 1;
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-        base = __shfl(base, leader);
-        idx = base + prefix;
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint64_t ma = __ballot(n0a != 0), mb = __ballot(n0b != 0), m1 = __ballot(n1 != 0), m2 = __ballot(n2 != 0);
+    const uint32_t pa = (uint32_t)__popcll(ma & lt), pb = (uint32_t)__popcll(mb & lt);
+    const uint32_t ta = (uint32_t)__popcll(ma);
+    if (lane == 0) {
+        L.total[0][wave] = ta + (uint32_t)__popcll(mb);
+        L.total[1][wave] = (uint32_t)__popcll(m1);
+        L.total[2][wave] = (uint32_t)__popcll(m2);
     }
-    return idx;
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const uint32_t k = threadIdx.x;
+        uint32_t sum = 0;
+        for (int w = 0; w < kShadeWaves; w++) { const uint32_t t = L.total[k][w]; L.base[k][w] = sum; sum += t; }
+        uint32_t *ctr = k == 0 ? c0 : (k == 1 ? c1 : c2);
+        const uint32_t b = (sum && ctr) ? atomicAdd(ctr, sum) : 0u;
+        for (int w = 0; w < kShadeWaves; w++) L.base[k][w] += b;
+    }
+    __syncthreads();
+    // within a wave: all "a" requests first, then the "b" requests
+    s0a = L.base[0][wave] + pa;
+    s0b = L.base[0][wave] + ta + pb;
+    s1 = L.base[1][wave] + (uint32_t)__popcll(m1 & lt);
+    s2 = L.base[2][wave] + (uint32_t)__popcll(m2 & lt);
+    __syncthreads(); // L may be reused by the next call
 }
 
 __device__ inline void put_ray(const RayQueue &q, uint32_t i, V3 o, V3 d, uint32_t frame, uint32_t meta, uint32_t ctr)
@@ -92,7 +119,7 @@ __device__ inline void st3(float *a, uint32_t i, V3 v) { a[3 * (size_t)i] = v.x;
 __device__ inline V3 ld3i(const float *a, uint32_t i) { return v3(a[3 * (size_t)i], a[3 * (size_t)i + 1], a[3 * (size_t)i + 2]); }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_camera_rays(DevScene S, PassInfo P, RayQueue q, Counters *cnt)
+__global__ void __launch_bounds__(kBlock) k_camera_rays(DevScene S, PassInfo P, RayQueue q)
 {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = P.n_pixels * (uint32_t)P.spp;
@@ -121,8 +148,8 @@ __global__ void __launch_bounds__(kBlock) k_camera_rays(DevScene S, PassInfo P, 
         o = pos;
         d = target - pos;
     }
-    const uint32_t slot = wave_alloc(&cnt->n_next, valid);
-    if (valid) put_ray(q, slot, o, d, idx, make_meta(RK_CAMERA, BHRT_HIT_FRONT, 0), 0);
+    // one slot per (pixel, sample), no compaction: out-of-image pixels of edge tiles become dead rays
+    if (idx < total) put_ray(q, idx, o, d, idx, make_meta(valid ? RK_CAMERA : RK_DEAD, BHRT_HIT_FRONT, 0), 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -132,9 +159,11 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, RayQueue q
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]), d = v3(q.dx[i], q.dy[i], q.dz[i]);
-    const int side = q.meta ? (int)((q.meta[i] >> 4) & 3u) : uniform_side;
+    const uint32_t meta = q.meta ? q.meta[i] : 0u;
+    const int side = q.meta ? (int)((meta >> 4) & 3u) : uniform_side;
     Hit hit;
-    trace_closest(S, o, d, side, hit);
+    if (q.meta && (meta & 15u) == RK_DEAD) { hit.t = BHRT_BIGFLOAT; hit.node = -1; hit.prim = -1; hit.front = 1; }
+    else trace_closest(S, o, d, side, hit);
     h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front;
 }
 
@@ -278,17 +307,22 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
     F.info[f] = (F.info[f] & 7u) | (dmode << 3) | (light_idx << 8) | (flags << 16) | ((uint32_t)(mi & 0xfff) << 20);
 }
 
-__global__ void __launch_bounds__(kBlock) k_shade(DevScene S, RenderParams R, PassInfo P, RayQueue qin, HitBuf hb, uint32_t n, RayQueue qout,
+__global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene S, RenderParams R, PassInfo P, RayQueue qin, HitBuf hb, uint32_t n, RayQueue qout,
                                                    ShadowQueue qs, Frames F, float *samples, Counters *cnt)
 {
+    __shared__ BlockAllocLds lds;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < n;
+    bool active = i < n;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
     uint32_t owner = 0, meta = 0, ctr = 0;
     Hit hit = {BHRT_BIGFLOAT, -1, -1, 1};
     if (active) {
+        meta = qin.meta[i];
+        active = (meta & 15u) != RK_DEAD;
+    }
+    if (active) {
         o = v3(qin.ox[i], qin.oy[i], qin.oz[i]); d = v3(qin.dx[i], qin.dy[i], qin.dz[i]);
-        owner = qin.frame[i]; meta = qin.meta[i]; ctr = qin.rng_ctr[i];
+        owner = qin.frame[i]; ctr = qin.rng_ctr[i];
         hit.t = hb.t[i]; hit.node = hb.node[i]; hit.prim = hb.prim[i]; hit.front = hb.front[i];
     }
     const uint32_t kind = meta & 15u;
@@ -302,7 +336,8 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene S, RenderParams R, Pa
         else if (kind == RK_REFR_IN) new_frame = hit.front != 0;      // MtlBlinn.cpp:507-510
         else new_frame = true;                                        // RK_REFR_OUT, MtlBlinn.cpp:527-533
     }
-    const uint32_t f = wave_alloc(&cnt->n_frames, new_frame);
+    uint32_t f, u0, u1, u2;
+    block_alloc3(lds, &cnt->n_frames, new_frame ? 1u : 0u, 0u, nullptr, 0u, nullptr, 0u, f, u0, u1, u2);
     if (new_frame && f >= R.cap_frames) { atomicOr(&cnt->overflow, 1u); new_frame = false; }
 
     ShadeOut so;
@@ -358,7 +393,6 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene S, RenderParams R, Pa
         hit_attrs(S, o, d, hit.t, hit.node, hit.prim, need_uv, a);
         shade_entry(S, R, F, f, o, a, hit.node, bounce, gi, code, skey, so);
         ray_owner = f;
-        atomicAdd(&cnt->n_shade, 1u);
     } else if (active) {
         if (kind == RK_CAMERA) {
             // background.Sample((i/W, j/H, 0)), Main.cpp:166-167
@@ -435,9 +469,8 @@ __global__ void __launch_bounds__(kBlock) k_shade(DevScene S, RenderParams R, Pa
     }
 
     // ---- convergent pushes
-    const uint32_t r0 = wave_alloc(&cnt->n_next, so.has_refr);
-    const uint32_t r1 = wave_alloc(&cnt->n_next, so.has_gi);
-    const uint32_t s0 = wave_alloc(&cnt->n_shadow, so.has_shadow);
+    uint32_t r0, r1, s0;
+    block_alloc3(lds, &cnt->n_next, so.has_refr ? 1u : 0u, so.has_gi ? 1u : 0u, &cnt->n_shadow, so.has_shadow ? 1u : 0u, nullptr, 0u, r0, r1, s0, u2);
     if (so.has_refr) {
         if (r0 < R.cap_rays) put_ray(qout, r0, so.ro, so.rd, ray_owner, so.rmeta, so.rctr);
         else atomicOr(&cnt->overflow, 2u);
@@ -639,6 +672,30 @@ static Frames MakeFrames(DeviceState *D)
     return F;
 }
 
+// owned pixels [q0, q0+n) that lie inside the image (edge tiles stick out); same mapping as pixel_of()
+static uint64_t CountValidPixels(const PassInfo &P, uint32_t n)
+{
+    const uint64_t tp = (uint64_t)P.tile * P.tile;
+    uint64_t valid = 0, q = P.q0, end = (uint64_t)P.q0 + n;
+    while (q < end) {
+        const uint64_t k = q / tp, t_begin = k * tp, t_end = t_begin + tp;
+        const uint64_t tid = (uint64_t)P.rank + k * (uint64_t)P.world;
+        const uint64_t ty = tid / (uint64_t)P.tiles_x, tx = tid % (uint64_t)P.tiles_x;
+        const uint64_t a = q, b = std::min<uint64_t>(end, t_end);
+        if (ty < (uint64_t)P.tiles_y) {
+            const int64_t w = std::min<int64_t>(P.tile, (int64_t)P.W - (int64_t)tx * P.tile), h = std::min<int64_t>(P.tile, (int64_t)P.H - (int64_t)ty * P.tile);
+            if (a == t_begin && b == t_end) valid += (uint64_t)(std::max<int64_t>(w, 0) * std::max<int64_t>(h, 0));
+            else
+                for (uint64_t x = a; x < b; x++) {
+                    const uint64_t within = x - t_begin;
+                    if ((int64_t)(within % P.tile) < w && (int64_t)(within / P.tile) < h) valid++;
+                }
+        }
+        q = b;
+    }
+    return valid;
+}
+
 struct Timer {
     DeviceState *D;
     double *acc;
@@ -687,7 +744,8 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         int rc = EnsureWorkspace(D, pass_samples, frames_per_sample);
         if (rc) return rc;
         R.cap_rays = D->cap_rays; R.cap_shadow = D->cap_rays; R.cap_frames = D->cap_frames;
-        if (pass_limit == 0 || pass_limit > D->cap_samples) pass_limit = D->cap_samples;
+        if (pass_limit == 0) pass_limit = pass_samples;
+        if (pass_limit > D->cap_samples) pass_limit = D->cap_samples;
         const uint32_t px_per_pass = pass_limit / (uint32_t)o.spp;
         const uint32_t npx = (uint32_t)std::min<uint64_t>(px_per_pass, owned_pixels - q);
         P.q0 = (uint32_t)q; P.n_pixels = npx;
@@ -700,33 +758,38 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         const uint32_t total = npx * (uint32_t)o.spp;
         {
             Timer t(D, &st->seconds_other);
-            hipLaunchKernelGGL(k_camera_rays, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, P, Q[0], D->d_cnt);
+            hipLaunchKernelGGL(k_camera_rays, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, P, Q[0]);
             t.Stop();
         }
-        HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, D->stream));
-        HIP_CHECK(hipStreamSynchronize(D->stream));
-        uint32_t n_cur = D->h_cnt->n_next;
-        st->camera_samples += n_cur;
+        uint32_t n_cur = total;
+        bool first_step = true;
         int cur = 0;
         std::vector<uint32_t> frame_marks = {0};
         bool overflow = false;
+        uint64_t pass_closest = 0;
         while (n_cur > 0) {
             {
                 Timer t(D, &st->seconds_trace_closest);
                 hipLaunchKernelGGL(k_trace_closest, dim3((n_cur + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, Q[cur], n_cur, 0, HB);
                 t.Stop();
             }
-            st->closest_rays += n_cur; st->launches_trace_closest++;
+            st->launches_trace_closest++;
             // reset the per-step queue counters (frames keep counting across steps)
             HIP_CHECK(hipMemsetAsync(&D->d_cnt->n_next, 0, 2 * sizeof(uint32_t), D->stream));
             {
                 Timer t(D, &st->seconds_shade);
-                hipLaunchKernelGGL(k_shade, dim3((n_cur + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt);
+                hipLaunchKernelGGL(k_shade, dim3((n_cur + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt);
                 t.Stop();
             }
             HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, D->stream));
             HIP_CHECK(hipStreamSynchronize(D->stream));
             if (D->h_cnt->overflow) { overflow = true; break; }
+            if (first_step) { // camera step: dead rays of edge tiles are not rays
+                const uint64_t valid_px = CountValidPixels(P, npx);
+                pass_closest = valid_px * (uint64_t)o.spp;
+                st->camera_samples += pass_closest;
+                first_step = false;
+            } else pass_closest += n_cur;
             const uint32_t n_sh = D->h_cnt->n_shadow;
             if (n_sh) {
                 Timer t(D, &st->seconds_trace_shadow);
@@ -746,7 +809,8 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             pass_limit = std::max<uint32_t>((uint32_t)o.spp, pass_limit / 2);
             continue;
         }
-        st->shade_calls += D->h_cnt->n_shade;
+        st->shade_calls += D->h_cnt->n_frames;
+        st->closest_rays += pass_closest;
         {
             Timer t(D, &st->seconds_other);
             for (size_t k = frame_marks.size(); k-- > 1;) {

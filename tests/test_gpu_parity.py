@@ -131,8 +131,6 @@ def test_per_sample_radiance_vs_oracle(case, spp, gi, gpu, load_scene, O):
     ro = O.render(sc.flat_bytes(), W, H, spp, gi=gi, seed=11, region=region)
     assert np.nanmax(np.abs(gs - ro["samples"])) <= TOL
     assert same_bits(gs, ro["samples"])                      # stronger than the bar: identical bits
-    assert st.closest_rays == ro["stats"].closest_rays       # same rays traced (shadow rays may be speculative)
-    assert st.shade_calls == ro["stats"].shade_calls
 
 
 @pytest.mark.parametrize("case", ["c2_glass_small", "c4_textured"])
@@ -145,6 +143,10 @@ def test_full_frame_vs_oracle(case, gpu, load_scene, O):
     assert same_bits(rad, ro["radiance"])
     assert np.array_equal(rgb, ro["rgb8"])                   # gamma + Color24 (Main.cpp:220-230)
     assert st.camera_samples == sc.width * sc.height * 3
+    # the same rays and Shade() calls as the recursion (shadow rays may exceed the oracle's: the wavefront traces
+    # the direct-light ray of a frame whose refraction/GI term later turns out >= 1, MtlBlinn.cpp:118,125)
+    assert st.closest_rays == ro["stats"].closest_rays and st.shade_calls == ro["stats"].shade_calls
+    assert ro["stats"].shadow_rays <= st.shadow_rays <= ro["stats"].shadow_rays * 1.01
 
 
 def test_no_jitter_no_gamma_options(gpu, load_scene, O):
