@@ -16,6 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libbhrt.so")
+CLI = os.path.join(HERE, "bhrt")
 
 HOST_SRCS = ["scene_host.cpp", "png_io.cpp", "capi_host.cpp"]
 HIP_SRCS = ["kernels.hip"]
@@ -52,6 +53,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs.append(obj)
     if force or _newer(objs, LIB):
         _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lz", "-o", LIB])
+    main_src = os.path.join(CSRC, "bhrt_main.cpp")
+    if force or _newer([main_src, LIB] + headers, CLI):  # the C++ host program above the C ABI (Main.cpp:418-431)
+        _run(["g++"] + COMMON + ["-Wall", main_src, "-L" + HERE, "-lbhrt", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + "/opt/rocm/lib", "-o", CLI])
     return LIB
 
 
