@@ -59,7 +59,7 @@ EXPORTS = [
     "bhrt_scene_warning", "bhrt_scene_flat", "bhrt_scene_upload", "bhrt_device_count",
     "bhrt_trace_closest_host", "bhrt_trace_closest_dev", "bhrt_trace_shadow_host", "bhrt_trace_shadow_dev",
     "bhrt_render", "bhrt_render_dev", "bhrt_render_samples", "bhrt_photon_build", "bhrt_photon_gather_host",
-    "bhrt_photon_export", "bhrt_save_png",
+    "bhrt_photon_get", "bhrt_photon_export", "bhrt_save_png",
 ]
 
 
@@ -191,6 +191,31 @@ class Scene:
         _check(lib().bhrt_render_dev(self._h, C.byref(opts), C.c_void_p(d_rgb8_ptr or None),
                                      C.c_void_p(d_radiance_ptr or None), C.byref(st), None))
         return st
+
+    # ---- caustic photon map ------------------------------------------------------------------
+    def photon_build(self, opts: Opts, max_photons: int) -> int:
+        n = C.c_uint32(0)
+        _check(lib().bhrt_photon_build(self._h, C.byref(opts), int(max_photons), C.byref(n)))
+        return n.value
+
+    def photon_get(self) -> np.ndarray:
+        """Balanced (heap-order) photon array as (n, 24) uint8 records (cyPhotonMap.h:72-90)."""
+        n = C.c_uint32(0)
+        _check(lib().bhrt_photon_get(self._h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 24), np.uint8)
+        _check(lib().bhrt_photon_get(self._h, _ptr(out), n.value, C.byref(n)))
+        return out
+
+    def photon_gather(self, p, nrm, radius=0.5):
+        p = np.ascontiguousarray(p, np.float32)
+        nrm = np.ascontiguousarray(nrm, np.float32)
+        irr = np.zeros_like(p)
+        d = np.zeros_like(p)
+        _check(lib().bhrt_photon_gather_host(self._h, _ptr(p), _ptr(nrm), C.c_size_t(p.shape[0]), C.c_float(radius), _ptr(irr), _ptr(d)))
+        return irr, d
+
+    def photon_export(self, path: str):
+        _check(lib().bhrt_photon_export(self._h, os.fsencode(path)))
 
     def render_samples(self, opts: Opts, x0, y0, x1, y1):
         out = np.zeros(((y1 - y0) * (x1 - x0), opts.spp, 3), np.float32)

@@ -70,6 +70,8 @@ struct Frames {
     float *rr;         // squared distance to the point light (PointLight.cpp:10-11)
     float *vis;        // Shadow() result (GenLight.cpp:10-13)
     float *caustic;    // 3: photon-map term brdf*irrad (:329-342), zero when off
+    // inputs of the caustic term, only allocated when the photon map is on: hit p, hit N, vV, kd sample, ks sample
+    float *ph_p, *ph_n, *ph_v, *ph_kd, *ph_ks;
 };
 
 struct Counters {

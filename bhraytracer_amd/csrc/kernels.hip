@@ -23,7 +23,8 @@
 #include <vector>
 
 #include "bhrt.h"
-#include "device_shade.h"
+#include "device_photon.h"
+#include "photon_host.h"
 #include "scene_internal.h"
 
 namespace bhrt {
@@ -304,6 +305,11 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
             st3(F.brdf, f, kd * cosTheta + ks * dm::powf_(dot(vH, vN), m.glossiness));
         }
     }
+    if (R.photon) { // inputs of the caustic term (MtlBlinn.cpp:329-342), evaluated by k_photon_gather_frames
+        st3(F.ph_p, f, a.p); st3(F.ph_n, f, a.N); st3(F.ph_v, f, vV);
+        st3(F.ph_kd, f, textured ? tc_sample_d(S, m.diffuse, a.uvw, a.du, a.dv) : ld3(m.diffuse.color));
+        st3(F.ph_ks, f, textured ? tc_sample_d(S, newSpecular, a.uvw, a.du, a.dv) : ld3(newSpecular.color));
+    }
     F.info[f] = (F.info[f] & 7u) | (dmode << 3) | (light_idx << 8) | (flags << 16) | ((uint32_t)(mi & 0xfff) << 20);
 }
 
@@ -574,6 +580,65 @@ __global__ void k_copy_samples(PassInfo P, const float *samples, int x0, int y0,
         for (int c = 0; c < 3; c++) out[(pix * P.spp + s) * 3 + c] = samples[((size_t)q * P.spp + s) * 3 + c];
 }
 
+// ------------------------------------------------------------------------------------------------
+// photon map kernels
+__global__ void __launch_bounds__(kBlock) k_photon_emit(DevScene S, uint32_t seed, uint64_t e0, uint32_t E, const int32_t *plights, int n_plights,
+                                                         float sum_intensity, DPhoton *tmp, uint32_t cap, uint32_t *counts)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    counts[i] = emit_photon_path(S, seed, e0 + i, plights, n_plights, sum_intensity, tmp + (size_t)i * cap, cap);
+}
+// stable compaction in emission order: path i's photons go to out[1 + offsets[i] + k] (slot 0 stays unused)
+__global__ void __launch_bounds__(kBlock) k_photon_compact(const DPhoton *tmp, uint32_t cap, const uint32_t *counts, const uint32_t *offsets, uint32_t E,
+                                                            uint32_t max_photons, DPhoton *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    const uint32_t c = counts[i], off = offsets[i];
+    for (uint32_t k = 0; k < c && k < cap; k++)
+        if (off + k < max_photons) out[1 + off + k] = tmp[(size_t)i * cap + k];
+}
+__global__ void __launch_bounds__(kBlock) k_photon_scale(DPhoton *photons, uint32_t n, float scale) // ScalePhotonPowers, cyPhotonMap.h:119
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) photons[1 + i].power *= scale;
+}
+// caustic term of frames [f0, f1): brdf * irradiance (MtlBlinn.cpp:329-342) -> F.caustic
+__global__ void __launch_bounds__(kBlock) k_photon_gather_frames(Frames F, uint32_t f0, uint32_t f1, const DPhoton *photons, int n, int half, float radius,
+                                                                  float *scr_d2, uint32_t *scr_idx, size_t stride, const bhrt_material *materials)
+{
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t f = f0 + lane;
+    if (f >= f1) return;
+    const uint32_t info = F.info[f];
+    if ((info >> 16) & FF_CONST) return;
+    const V3 p = ld3i(F.ph_p, f), N = ld3i(F.ph_n, f), vV = ld3i(F.ph_v, f);
+    V3 irr, vL;
+    if (!photon_estimate(photons, n, half, p, N, radius, scr_d2 + lane, scr_idx + lane, stride, irr, vL)) {
+        // no photon found: irrad = 0 and vL = (0,0,0) -> cosTheta = -0 is not > 0: no contribution
+        return;
+    }
+    const V3 vN = normalized(N);
+    const float cosTheta = -dot(vL, vN);
+    if (cosTheta > 0) {
+        const V3 vH = normalized(vL + vV);
+        const float gloss = materials[(info >> 20) & 0xfffu].glossiness;
+        const V3 brdf = ld3i(F.ph_kd, f) + ld3i(F.ph_ks, f) * dm::powf_(dot(vH, vN), gloss) / cosTheta;
+        st3(F.caustic, f, brdf * irr);
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_photon_gather_api(const float *p, const float *nrm, uint32_t cnt, const DPhoton *photons, int n, int half, float radius,
+                                                               float *scr_d2, uint32_t *scr_idx, size_t stride, float *irrad, float *dir)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    V3 irr, d;
+    photon_estimate(photons, n, half, ld3i(p, i), ld3i(nrm, i), radius, scr_d2 + i, scr_idx + i, stride, irr, d);
+    st3(irrad, i, irr);
+    st3(dir, i, d);
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -598,6 +663,15 @@ struct DeviceState {
     Counters *h_cnt = nullptr; // pinned
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    // caustic photon map (balanced, heap order, slot 0 unused) + gather scratch
+    DPhoton *d_photons = nullptr;
+    uint32_t n_photons = 0;
+    std::vector<HostPhoton> h_photons; // balanced copy for bhrt_photon_export
+    float *d_ph_frames = nullptr;      // 15 * cap_frames floats (p, N, V, kd, ks per frame), only with photon_map
+    uint32_t ph_frames_cap = 0;
+    float *d_scr_d2 = nullptr;
+    uint32_t *d_scr_idx = nullptr;
+    uint32_t scr_lanes = 0;
     // scratch for the public trace API
     float *d_api_f = nullptr;
     int32_t *d_api_i = nullptr;
@@ -612,7 +686,7 @@ void DestroyDeviceState(DeviceState *d)
     fr(d->d_blob); fr(d->d_chain);
     for (int k = 0; k < 2; k++) { fr(d->d_rayf[k]); fr(d->d_rayu[k]); }
     fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_cnt);
-    fr(d->d_api_f); fr(d->d_api_i);
+    fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr_d2); fr(d->d_scr_idx);
     if (d->h_cnt) (void)hipHostFree(d->h_cnt);
     for (int k = 0; k < 2; k++) if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -656,6 +730,7 @@ static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, uint32_t frames
     HIP_CHECK(hipMalloc(&D->d_ff, cf * 23 * sizeof(float)));
     HIP_CHECK(hipMalloc(&D->d_samples, (size_t)cap_samples * 3 * sizeof(float)));
     D->cap_samples = cap_samples; D->cap_rays = (uint32_t)cr; D->cap_frames = (uint32_t)cf;
+    if (D->d_ph_frames) { (void)hipFree(D->d_ph_frames); D->d_ph_frames = nullptr; D->ph_frames_cap = 0; }
     return BHRT_OK;
 }
 
@@ -669,6 +744,8 @@ static Frames MakeFrames(DeviceState *D)
     F.mult = p; p += 3 * c; F.refr = p; p += 3 * c; F.gi = p; p += 3 * c; F.gi_mult = p; p += 3 * c;
     F.brdf = p; p += 3 * c; F.refr_color = p; p += 3 * c; F.caustic = p; p += 3 * c;
     F.rr = p; p += c; F.vis = p;
+    float *q = D->d_ph_frames;
+    F.ph_p = q; F.ph_n = q ? q + 3 * c : nullptr; F.ph_v = q ? q + 6 * c : nullptr; F.ph_kd = q ? q + 9 * c : nullptr; F.ph_ks = q ? q + 12 * c : nullptr;
     return F;
 }
 
@@ -710,6 +787,19 @@ struct Timer {
     }
 };
 
+static int EnsurePhotonScratch(DeviceState *D, uint32_t lanes)
+{
+    if (D->scr_lanes >= lanes) return BHRT_OK;
+    if (D->d_scr_d2) (void)hipFree(D->d_scr_d2);
+    if (D->d_scr_idx) (void)hipFree(D->d_scr_idx);
+    D->d_scr_d2 = nullptr; D->d_scr_idx = nullptr; D->scr_lanes = 0;
+    HIP_CHECK(hipMalloc(&D->d_scr_d2, (size_t)lanes * (BHRT_PHOTON_K + 1) * sizeof(float)));
+    HIP_CHECK(hipMalloc(&D->d_scr_idx, (size_t)lanes * (BHRT_PHOTON_K + 1) * sizeof(uint32_t)));
+    D->scr_lanes = lanes;
+    return BHRT_OK;
+}
+
+
 // Renders owned pixels [q_begin, q_end) of this rank; samples_out (device) receives the per-sample buffer
 // of the region when requested (parity tests).
 static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, float *d_radiance, bhrt_stats *st, float *d_region_samples, int x0,
@@ -744,6 +834,16 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         int rc = EnsureWorkspace(D, pass_samples, frames_per_sample);
         if (rc) return rc;
         R.cap_rays = D->cap_rays; R.cap_shadow = D->cap_rays; R.cap_frames = D->cap_frames;
+        if (o.photon_map) {
+            if (D->ph_frames_cap < D->cap_frames) {
+                if (D->d_ph_frames) (void)hipFree(D->d_ph_frames);
+                D->d_ph_frames = nullptr;
+                HIP_CHECK(hipMalloc(&D->d_ph_frames, (size_t)D->cap_frames * 15 * sizeof(float)));
+                D->ph_frames_cap = D->cap_frames;
+            }
+            rc = EnsurePhotonScratch(D, 1u << 20);
+            if (rc) return rc;
+        }
         if (pass_limit == 0) pass_limit = pass_samples;
         if (pass_limit > D->cap_samples) pass_limit = D->cap_samples;
         const uint32_t px_per_pass = pass_limit / (uint32_t)o.spp;
@@ -796,6 +896,15 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 hipLaunchKernelGGL(k_trace_shadow, dim3((n_sh + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, SQ, n_sh, F.vis);
                 t.Stop();
                 st->shadow_rays += n_sh; st->launches_trace_shadow++;
+            }
+            if (o.photon_map && D->h_cnt->n_frames > frame_marks.back()) { // caustic term of the frames opened in this step
+                Timer t(D, &st->reserved[0]);
+                for (uint32_t fb = frame_marks.back(); fb < D->h_cnt->n_frames; fb += D->scr_lanes) {
+                    const uint32_t fe = std::min<uint32_t>(D->h_cnt->n_frames, fb + D->scr_lanes);
+                    hipLaunchKernelGGL(k_photon_gather_frames, dim3((fe - fb + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, F, fb, fe, D->d_photons, (int)D->n_photons,
+                                       (int)D->n_photons / 2 - 1, 0.5f /* MAX_Area, MtlBlinn.cpp:29 */, D->d_scr_d2, D->d_scr_idx, (size_t)D->scr_lanes, D->S.materials);
+                }
+                t.Stop();
             }
             frame_marks.push_back(D->h_cnt->n_frames);
             n_cur = D->h_cnt->n_next;
@@ -991,7 +1100,7 @@ int bhrt_render_dev(bhrt_scene *scene, const bhrt_opts *opts, uint8_t *d_rgb8, f
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     if (!opts) { SetError("null opts"); return BHRT_ERR_ARG; }
-    if (opts->photon_map) { SetError("photon-map gather is not available in this build"); return BHRT_ERR_UNSUPPORTED; }
+    if (opts->photon_map && !scene->dev->d_photons) { SetError("photon_map = 1 needs bhrt_photon_build first"); return BHRT_ERR_ARG; }
     bhrt_stats local;
     memset(&local, 0, sizeof local);
     rc = RenderRange(scene, *opts, d_rgb8, d_radiance, &local, nullptr, 0, 0, 0, 0);
@@ -1026,7 +1135,7 @@ int bhrt_render_samples(bhrt_scene *scene, const bhrt_opts *opts, int x0, int y0
     if (!opts || !samples) { SetError("null argument"); return BHRT_ERR_ARG; }
     const bhrt_flat_header *H = scene->flat.hdr();
     if (x0 < 0 || y0 < 0 || x1 > H->camera.width || y1 > H->camera.height || x0 >= x1 || y0 >= y1) { SetError("bad region"); return BHRT_ERR_ARG; }
-    if (opts->photon_map) { SetError("photon-map gather is not available in this build"); return BHRT_ERR_UNSUPPORTED; }
+    if (opts->photon_map && !scene->dev->d_photons) { SetError("photon_map = 1 needs bhrt_photon_build first"); return BHRT_ERR_ARG; }
     const size_t nfl = (size_t)(x1 - x0) * (y1 - y0) * opts->spp * 3;
     float *d_s = nullptr;
     HIP_CHECK(hipMalloc(&d_s, nfl * sizeof(float)));
@@ -1040,8 +1149,129 @@ int bhrt_render_samples(bhrt_scene *scene, const bhrt_opts *opts, int x0, int y0
     return rc;
 }
 
-int bhrt_photon_build(bhrt_scene *, const bhrt_opts *, uint32_t, uint32_t *) { SetError("photon map: not available in this build"); return BHRT_ERR_UNSUPPORTED; }
-int bhrt_photon_gather_host(bhrt_scene *, const float *, const float *, size_t, float, float *, float *) { SetError("photon map: not available in this build"); return BHRT_ERR_UNSUPPORTED; }
-int bhrt_photon_export(const bhrt_scene *, const char *) { SetError("photon map: not available in this build"); return BHRT_ERR_UNSUPPORTED; }
+// ---- caustic photon map --------------------------------------------------------------------------
+int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, uint32_t *n_stored)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    if (!opts || max_photons == 0 || max_photons > (1u << 28)) { SetError("bad photon budget"); return BHRT_ERR_ARG; }
+    DeviceState *D = scene->dev;
+    const bhrt_flat_header *H = scene->flat.hdr();
+    const bhrt_light *lights = (const bhrt_light *)(scene->flat.blob.data() + H->off_lights);
+    // BuildCausticPhotonMap, Main.cpp:346-361: point lights sorted by Gray * GetSize() (int size, lights.h:76)
+    std::vector<int32_t> pl;
+    for (uint32_t i = 0; i < H->n_lights; i++)
+        if (lights[i].type == BHRT_LIGHT_POINT) pl.push_back((int32_t)i);
+    if (pl.empty()) { SetError("photon map: the scene has no point light (BuildCausticPhotonMap returns false)"); return BHRT_ERR_UNSUPPORTED; }
+    auto key = [&](int32_t i) { return ((lights[i].intensity[0] + lights[i].intensity[1] + lights[i].intensity[2]) / 3.0f) * (int)lights[i].size; };
+    std::sort(pl.begin(), pl.end(), [&](int32_t a, int32_t b) { return key(a) < key(b); });
+    float sum = 0;
+    for (int32_t i : pl) sum += key(i);
+
+    if (D->d_photons) { (void)hipFree(D->d_photons); D->d_photons = nullptr; D->n_photons = 0; }
+    DPhoton *d_out = nullptr, *d_tmp = nullptr;
+    uint32_t *d_counts = nullptr, *d_offsets = nullptr;
+    int32_t *d_pl = nullptr;
+    auto cleanup = [&]() { if (d_tmp) (void)hipFree(d_tmp); if (d_counts) (void)hipFree(d_counts); if (d_offsets) (void)hipFree(d_offsets); if (d_pl) (void)hipFree(d_pl); };
+    HIP_CHECK(hipMalloc(&d_out, ((size_t)max_photons + 1) * sizeof(DPhoton)));
+    HIP_CHECK(hipMemset(d_out, 0, ((size_t)max_photons + 1) * sizeof(DPhoton)));
+    const uint32_t E = 1u << 20; // emissions per batch
+    uint32_t cap = 8;            // photons one path may store before the batch is redone with more room
+    HIP_CHECK(hipMalloc(&d_counts, E * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&d_offsets, E * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&d_pl, pl.size() * sizeof(int32_t)));
+    HIP_CHECK(hipMemcpy(d_pl, pl.data(), pl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMalloc(&d_tmp, (size_t)E * cap * sizeof(DPhoton)));
+    std::vector<uint32_t> counts(E), offsets(E);
+    uint64_t e0 = 0, stored = 0;
+    const uint64_t emission_budget = (uint64_t)max_photons * 4096ull + (1ull << 24);
+    while (stored < max_photons && e0 < emission_budget) {
+        hipLaunchKernelGGL(k_photon_emit, dim3(E / kBlock), dim3(kBlock), 0, D->stream, D->S, opts->seed, e0, E, d_pl, (int)pl.size(), sum, d_tmp, cap, d_counts);
+        HIP_CHECK(hipMemcpyAsync(counts.data(), d_counts, E * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
+        HIP_CHECK(hipStreamSynchronize(D->stream));
+        uint32_t maxc = 0;
+        for (uint32_t i = 0; i < E; i++) maxc = std::max(maxc, counts[i]);
+        if (maxc > cap) { // a path stored more than `cap` photons: redo this batch with room for all of them
+            (void)hipFree(d_tmp);
+            d_tmp = nullptr;
+            cap = maxc;
+            HIP_CHECK(hipMalloc(&d_tmp, (size_t)E * cap * sizeof(DPhoton)));
+            continue;
+        }
+        uint64_t run = stored;
+        for (uint32_t i = 0; i < E; i++) { offsets[i] = (uint32_t)std::min<uint64_t>(run, max_photons); run += counts[i]; }
+        HIP_CHECK(hipMemcpyAsync(d_offsets, offsets.data(), E * sizeof(uint32_t), hipMemcpyHostToDevice, D->stream));
+        hipLaunchKernelGGL(k_photon_compact, dim3(E / kBlock), dim3(kBlock), 0, D->stream, d_tmp, cap, d_counts, d_offsets, E, max_photons, d_out);
+        HIP_CHECK(hipStreamSynchronize(D->stream));
+        stored = run;
+        e0 += E;
+    }
+    cleanup();
+    const uint32_t n = (uint32_t)std::min<uint64_t>(stored, max_photons);
+    if (n == 0) { (void)hipFree(d_out); SetError("photon map: no photon reached a photon surface"); return BHRT_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(k_photon_scale, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, d_out, n, 1.f / (float)(int)n); // Main.cpp:380
+    // PrepareForIrradianceEstimation on the host (cyPhotonMap.h:236-258), then back to HBM
+    D->h_photons.assign((size_t)n + 1, HostPhoton());
+    HIP_CHECK(hipMemcpyAsync(D->h_photons.data(), d_out, ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyDeviceToHost, D->stream));
+    HIP_CHECK(hipStreamSynchronize(D->stream));
+    memset(&D->h_photons[0], 0, sizeof(HostPhoton));
+    BalancePhotons(D->h_photons);
+    HIP_CHECK(hipMemcpy(d_out, D->h_photons.data(), ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyHostToDevice));
+    D->d_photons = d_out;
+    D->n_photons = n;
+    if (n_stored) *n_stored = n;
+    return BHRT_OK;
+}
+
+int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *nrm, size_t cnt, float radius, float *irrad, float *dir)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    DeviceState *D = scene->dev;
+    if (!D->d_photons) { SetError("photon map: call bhrt_photon_build first"); return BHRT_ERR_ARG; }
+    if (!p || !nrm || !irrad || !dir) { SetError("null buffer"); return BHRT_ERR_ARG; }
+    if (cnt == 0) return BHRT_OK;
+    const uint32_t chunk = 1u << 18;
+    rc = EnsurePhotonScratch(D, chunk);
+    if (rc) return rc;
+    float *d_buf = nullptr;
+    HIP_CHECK(hipMalloc(&d_buf, (size_t)chunk * 12 * sizeof(float)));
+    for (size_t b = 0; b < cnt; b += chunk) {
+        const uint32_t m = (uint32_t)std::min<size_t>(chunk, cnt - b);
+        HIP_CHECK(hipMemcpy(d_buf, p + b * 3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_buf + (size_t)chunk * 3, nrm + b * 3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_photon_gather_api, dim3((m + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, d_buf, d_buf + (size_t)chunk * 3, m, D->d_photons, (int)D->n_photons,
+                           (int)D->n_photons / 2 - 1, radius, D->d_scr_d2, D->d_scr_idx, (size_t)D->scr_lanes, d_buf + (size_t)chunk * 6, d_buf + (size_t)chunk * 9);
+        HIP_CHECK(hipStreamSynchronize(D->stream));
+        HIP_CHECK(hipMemcpy(irrad + b * 3, d_buf + (size_t)chunk * 6, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(dir + b * 3, d_buf + (size_t)chunk * 9, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_buf);
+    return BHRT_OK;
+}
+
+int bhrt_photon_get(const bhrt_scene *scene, void *photons_out, uint32_t capacity, uint32_t *n)
+{
+    if (!scene || !scene->dev || scene->dev->h_photons.empty()) { SetError("photon map: nothing built"); return BHRT_ERR_ARG; }
+    const uint32_t have = scene->dev->n_photons;
+    if (n) *n = have;
+    if (photons_out) {
+        if (capacity < have) { SetError("photon buffer too small"); return BHRT_ERR_ARG; }
+        memcpy(photons_out, &scene->dev->h_photons[1], (size_t)have * sizeof(HostPhoton));
+    }
+    return BHRT_OK;
+}
+
+int bhrt_photon_export(const bhrt_scene *scene, const char *dat_path)
+{
+    if (!scene || !scene->dev || scene->dev->h_photons.empty() || !dat_path) { SetError("photon map: nothing to export"); return BHRT_ERR_ARG; }
+    FILE *fp = fopen(dat_path, "wb"); // fwrite(GetPhotons(), sizeof(Photon), NumPhotons(), fp), Main.cpp:383-385
+    if (!fp) { SetError(std::string("cannot write ") + dat_path); return BHRT_ERR_IO; }
+    const size_t n = scene->dev->n_photons;
+    const bool ok = fwrite(&scene->dev->h_photons[1], sizeof(HostPhoton), n, fp) == n;
+    fclose(fp);
+    if (!ok) { SetError("short write"); return BHRT_ERR_IO; }
+    return BHRT_OK;
+}
 
 } // extern "C"

@@ -78,7 +78,7 @@ typedef struct bhrt_stats {
     double seconds_total;    /* wall clock of the call, scene already resident */
     double seconds_trace_closest, seconds_trace_shadow, seconds_shade, seconds_other; /* HIP-event kernel time */
     uint64_t launches_trace_closest, launches_trace_shadow;
-    double reserved[4];
+    double reserved[4]; /* [0] = seconds in the photon gather kernel */
 } bhrt_stats;
 
 /* compact hit record written by the trace kernel (SoA on the device: one array per field) */
@@ -126,6 +126,7 @@ int bhrt_render_samples(bhrt_scene *scene, const bhrt_opts *opts, int x0, int y0
 /* ---- caustic photon map (Main.cpp:342-386, DataStructure/cyPhotonMap.h) -------------------------- */
 int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, uint32_t *n_stored);
 int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *n, size_t cnt, float radius, float *irrad, float *dir);
+int bhrt_photon_get(const bhrt_scene *scene, void *photons_out /* 24 B records, balanced order */, uint32_t capacity, uint32_t *n);
 int bhrt_photon_export(const bhrt_scene *scene, const char *dat_path); /* 24-byte records, Main.cpp:383-385 */
 
 /* ---- image output (RenderImage::SaveImage, Scenes/scene.h:628-644) ------------------------------- */

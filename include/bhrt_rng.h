@@ -59,6 +59,17 @@ static inline BHRT_HD uint32_t bhrt_section_key(uint32_t sample_key, uint64_t pa
     return bhrt_mix32(k + section * 0x1B56C4E9U + 0x7F4A7C15U);
 }
 
+/* photon pass (Main.cpp:342-386): the reference's emission loop is one long sequential rand() sequence.
+ * sequential mode: ONE stream for the whole loop (key below with emission = all ones);
+ * keyed mode: one stream per emission index, counter runs along that photon's path. */
+static inline BHRT_HD uint32_t bhrt_photon_key_sequential(uint32_t seed) { return bhrt_sample_key(seed, 0xFFFFFFFFu, 0x50484F54u); }
+static inline BHRT_HD uint32_t bhrt_photon_key(uint32_t seed, uint64_t emission)
+{
+    uint32_t k = bhrt_photon_key_sequential(seed);
+    k = bhrt_mix32(k ^ bhrt_mix32((uint32_t)emission + 0x3C6EF372U));
+    return bhrt_mix32(k ^ bhrt_mix32((uint32_t)(emission >> 32) + 0x9E3779B9U));
+}
+
 /* the counter-th draw of stream `key`: an int in [0, BHRT_RAND_MAX] like rand() */
 static inline BHRT_HD int32_t bhrt_rand31(uint32_t key, uint32_t counter)
 {

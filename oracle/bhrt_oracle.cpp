@@ -1287,12 +1287,430 @@ extern "C" int oracle_bvh_build(const float *v, const uint32_t *f, uint32_t nf, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// photon map: placeholder until the photon section is restated
+// caustic photon map: DataStructure/cyPhotonMap.h, Main.cpp:319-386, MtlBlinn.cpp:203-303, PointLight.cpp:20-34
 // ------------------------------------------------------------------------------------------------
 namespace {
-struct PhotonMapView {};
-bool PhotonEstimate(const PhotonMapView *, Color &, Vec3 &, float, const Vec3 &, const Vec3 &) { return false; }
+
+#pragma pack(push, 1)
+struct Photon { // cyPhotonMap.h:72-90, 24 bytes (= the record of Resource/causticPhotonMap.dat and of PhotonMapViz.cpp:30-36)
+    float pos[3];
+    float power;
+    uint8_t color[3];
+    uint8_t planeAndDirZ;
+    int16_t dirX, dirY;
+};
+#pragma pack(pop)
+static_assert(sizeof(Photon) == 24, "photon record must be 24 bytes");
+
+struct PhotonMapView {
+    std::vector<Photon> photons; // slot 0 unused (zero), photons 1..n
+    int numStored = 0, halfStored = 0;
+    std::vector<Photon> unbalanced;
+};
+PhotonMapView g_pm_storage;
+
+inline void PhotonSetPower(Photon &p, const Color &c) // cyPhotonMap.h:172-178
+{
+    p.power = c.r;
+    if (p.power < c.g) p.power = c.g;
+    if (p.power < c.b) p.power = c.b;
+    Color q = c / p.power;
+    p.color[0] = FloatToByte(q.r); p.color[1] = FloatToByte(q.g); p.color[2] = FloatToByte(q.b);
+}
+inline void PhotonSetDirection(Photon &p, const Vec3 &dir) // cyPhotonMap.h:180-190
+{
+    p.dirX = (int16_t)(dir.x * 0x7FFF);
+    p.dirY = (int16_t)(dir.y * 0x7FFF);
+    if (dir.z > 0) p.planeAndDirZ &= 0x7;
+    else p.planeAndDirZ = 0x8 | (p.planeAndDirZ & 0x7);
+}
+inline Vec3 PhotonGetDirection(const Photon &p) // cyPhotonMap.h:192-214 incl. the missing dirY^2
+{
+    Vec3 dir;
+    dir.x = float(p.dirX) / float(0x7FFF);
+    dir.y = float(p.dirY) / float(0x7FFF);
+    int dirXY2 = p.dirX * p.dirX + p.dirY - p.dirY;
+    if (dirXY2 > 0x3FFF0001) dirXY2 = 0x3FFF0001;
+    int dirZ2 = 0x3FFF0001 - dirXY2;
+    int dirZ = 0, place = 0x40000000, remainder = dirZ2;
+    while (place > remainder) place = place >> 2;
+    while (place) {
+        if (remainder >= dirZ + place) { remainder = remainder - dirZ - place; dirZ = dirZ + (place << 1); }
+        dirZ = dirZ >> 1;
+        place = place >> 2;
+    }
+    dir.z = float(dirZ) / float(0x7FFF);
+    if (p.planeAndDirZ & 0x8) dir.z = -dir.z;
+    return dir;
+}
+inline Color PhotonGetPower(const Photon &p) { return Color(p.color[0] / 255.0f, p.color[1] / 255.0f, p.color[2] / 255.0f) * p.power; } // cyColor ToColor * power
+
+// PhotonMap::BalanceSegment, cyPhotonMap.h:262-328
+void BalanceSegment(std::vector<Photon> &photons, std::vector<Photon> &balanced, const Vec3 &boxMin, const Vec3 &boxMax, int index, int start, int end)
+{
+    int median = 1;
+    while ((4 * median) <= (end - start + 1)) median += median;
+    if ((3 * median) <= (end - start + 1)) { median += median; median += start - 1; }
+    else median = end - median + 1;
+    int axis = 2;
+    Vec3 boxDif = boxMax - boxMin;
+    if (boxDif.x > boxDif.y) { if (boxDif.x > boxDif.z) axis = 0; }
+    else if (boxDif.y > boxDif.z) axis = 1;
+    int left = start, right = end;
+    auto swapP = [&](int i, int j) { Photon t = photons[i]; photons[i] = photons[j]; photons[j] = t; };
+    while (right > left) {
+        const float v = photons[right].pos[axis];
+        int i = left - 1, j = right;
+        while (photons[++i].pos[axis] < v) {}
+        while (photons[--j].pos[axis] > v && j > left) {}
+        while (i < j) {
+            swapP(i, j);
+            while (photons[++i].pos[axis] < v) {}
+            while (photons[--j].pos[axis] > v && j > left) {}
+        }
+        swapP(i, right);
+        if (i >= median) right = i - 1;
+        if (i <= median) left = i + 1;
+    }
+    balanced[index] = photons[median];
+    balanced[index].planeAndDirZ = (balanced[index].planeAndDirZ & 0x8) | (axis & 0x3); // SetPlane
+    if (median > start) {
+        if (start < median - 1) {
+            Vec3 tMax = boxMax;
+            (&tMax.x)[axis] = balanced[index].pos[axis];
+            BalanceSegment(photons, balanced, boxMin, tMax, 2 * index, start, median - 1);
+        } else balanced[2 * index] = photons[start];
+    }
+    if (median < end) {
+        if (median + 1 < end) {
+            Vec3 tMin = boxMin;
+            (&tMin.x)[axis] = balanced[index].pos[axis];
+            BalanceSegment(photons, balanced, tMin, boxMax, 2 * index + 1, median + 1, end);
+        } else balanced[2 * index + 1] = photons[end];
+    }
+}
+// PhotonMap::PrepareForIrradianceEstimation, cyPhotonMap.h:236-258 (bbox starts from the unused slot 0, Q11)
+void PreparePhotonMap(PhotonMapView &pm)
+{
+    if (pm.photons.empty() || pm.numStored == 0) return;
+    Vec3 boxMin(pm.photons[0].pos[0], pm.photons[0].pos[1], pm.photons[0].pos[2]), boxMax = boxMin;
+    for (int i = 1; i <= pm.numStored; i++) {
+        const float *q = pm.photons[i].pos;
+        if (boxMin.x > q[0]) boxMin.x = q[0];
+        if (boxMax.x < q[0]) boxMax.x = q[0];
+        if (boxMin.y > q[1]) boxMin.y = q[1];
+        if (boxMax.y < q[1]) boxMax.y = q[1];
+        if (boxMin.z > q[2]) boxMin.z = q[2];
+        if (boxMax.z < q[2]) boxMax.z = q[2];
+    }
+    std::vector<Photon> balanced(pm.numStored + 1);
+    memset(balanced.data(), 0, sizeof(Photon) * balanced.size());
+    BalanceSegment(pm.photons, balanced, boxMin, boxMax, 1, 1, pm.numStored);
+    balanced.swap(pm.photons);
+    pm.halfStored = pm.numStored / 2 - 1;
+}
+
+// PhotonMap::LocatePhotons, cyPhotonMap.h:421-498 (normScale == 0: ellipticity 1 as called at MtlBlinn.cpp:334)
+struct Nearest {
+    Vec3 pos, normal;
+    int maxPhotons, found;
+    float *dist2;
+    int *idx;
+};
+void LocatePhotons(const PhotonMapView &pm, Nearest &np, int index)
+{
+    const Photon &p = pm.photons[index];
+    int axis = p.planeAndDirZ & 0x3;
+    if (index < pm.halfStored) {
+        float dist = (&np.pos.x)[axis] - p.pos[axis];
+        if (dist > 0) {
+            LocatePhotons(pm, np, 2 * index + 1);
+            if (dist * dist < np.dist2[0]) LocatePhotons(pm, np, 2 * index);
+        } else {
+            LocatePhotons(pm, np, 2 * index);
+            if (dist * dist < np.dist2[0]) LocatePhotons(pm, np, 2 * index + 1);
+        }
+    }
+    Vec3 dif = Vec3(p.pos[0], p.pos[1], p.pos[2]) - np.pos;
+    float dist2 = dif.LengthSquared();
+    if (dist2 < np.dist2[0]) {
+        Vec3 dir = PhotonGetDirection(p);
+        if (dir.Dot(np.normal) >= 0) return;
+        if (np.found < np.maxPhotons) {
+            np.found++;
+            np.dist2[np.found] = dist2;
+            np.idx[np.found] = index;
+            if (np.found == np.maxPhotons) { // build a max-heap
+                int half_found = np.found >> 1;
+                for (int k = half_found; k >= 1; k--) {
+                    int parent = k;
+                    int tp = np.idx[k];
+                    float td2 = np.dist2[k];
+                    while (parent <= half_found) {
+                        int j = parent + parent;
+                        if (j < np.found && np.dist2[j] < np.dist2[j + 1]) j++;
+                        if (td2 >= np.dist2[j]) break;
+                        np.dist2[parent] = np.dist2[j];
+                        np.idx[parent] = np.idx[j];
+                        parent = j;
+                    }
+                    np.idx[parent] = tp;
+                    np.dist2[parent] = td2;
+                }
+            }
+        } else {
+            int parent = 1, j = 2;
+            while (j <= np.found) {
+                if (j < np.found && np.dist2[j] < np.dist2[j + 1]) j++;
+                if (dist2 > np.dist2[j]) break;
+                np.dist2[parent] = np.dist2[j];
+                np.idx[parent] = np.idx[j];
+                parent = j;
+                j <<= 1;
+            }
+            np.idx[parent] = index;
+            np.dist2[parent] = dist2;
+            np.dist2[0] = np.dist2[1];
+        }
+    }
+}
+// PhotonMap::EstimateIrradiance<1000>(irrad, direction, radius, pos, &normal), cyPhotonMap.h:332-382 (constant filter)
+bool PhotonEstimate(const PhotonMapView *pm, Color &irrad, Vec3 &direction, float radius, const Vec3 &pos, const Vec3 &normal)
+{
+    irrad = Black();
+    direction = Vec3(0, 0, 0);
+    if (!pm || pm->numStored == 0) return false;
+    const int maxPhotons = 1000; // MAX_PhotonCountInArea, MtlBlinn.cpp:28
+    float found_dist2[maxPhotons + 1];
+    int found_idx[maxPhotons + 1];
+    Nearest np;
+    np.pos = pos; np.normal = normal; np.maxPhotons = maxPhotons; np.found = 0; np.dist2 = found_dist2; np.idx = found_idx;
+    np.dist2[0] = radius * radius;
+    LocatePhotons(*pm, np, 1);
+    for (int i = 1; i <= np.found; i++) {
+        const Photon &ph = pm->photons[np.idx[i]];
+        Color power = PhotonGetPower(ph);
+        float filter = 1;
+        irrad += filter * power;
+        Vec3 dir = PhotonGetDirection(ph);
+        direction = direction + dir * (filter * ph.power);
+    }
+    if (np.found > 0) {
+        float area = (float)M_PI * np.dist2[0];
+        if (area > 0) {
+            const float one_over_area = 1.0f / area;
+            irrad = irrad * one_over_area;
+        }
+        direction = direction / direction.Length(); // Normalize()
+    }
+    return np.found > 0;
+}
+
+// photon emission -------------------------------------------------------------------------------
+template <class M> struct PhotonTracer {
+    const Scene &S;
+    Tracer<M> T;
+    Textures<M> X;
+    Rng rng;
+    Shader<M> sh;
+    PhotonMapView &pm;
+    int maxPhotons;
+    PhotonTracer(const Scene &s, PhotonMapView &p, int maxp) : S(s), T(s, nullptr), X(s), sh(s, T, X, rng, nullptr, false), pm(p), maxPhotons(maxp) {}
+
+    bool AddPhoton(const Vec3 &pos, const Vec3 &dir, const Color &power) // cyPhotonMap.h:218-232
+    {
+        if (pm.numStored >= maxPhotons) return false;
+        int i = ++pm.numStored;
+        Photon p;
+        memset(&p, 0, sizeof p); // the reference leaves planeAndDirZ's low bits uninitialised; zero here
+        p.pos[0] = pos.x; p.pos[1] = pos.y; p.pos[2] = pos.z;
+        PhotonSetDirection(p, dir);
+        PhotonSetPower(p, power);
+        pm.photons[i] = p;
+        return true;
+    }
+    // MtlBlinn::RandomPhotonBounceForCaustic, MtlBlinn.cpp:203-303
+    bool BounceForCaustic(const bhrt_material &m, Ray &r, Color &c, const HitInfo &hInfo)
+    {
+        float rnd = rng.Rnd01();
+        Vec3 vN = hInfo.N.GetNormalized();
+        Vec3 vV = -(r.dir.GetNormalized());
+        Color refrC(m.refraction.color[0], m.refraction.color[1], m.refraction.color[2]);
+        if (refrC.Gray() > 0) {
+            float cosPhi1 = vN.Dot(vV);
+            float sinPhi1 = sqrtf(1 - cosPhi1 * cosPhi1);
+            float sinPhi2 = sinPhi1 / m.ior;
+            float cosPhi2 = sqrtf(1 - sinPhi2 * sinPhi2);
+            Vec3 vTn = -cosPhi2 * vN;
+            Vec3 vNxV = vN.Cross(vV);
+            Vec3 vTp = vN.Cross(vNxV).GetNormalized() * sinPhi2;
+            Vec3 vT = vTn + vTp;
+            Ray in;
+            in.dir = vT;
+            in.p = hInfo.p - vN * O_BIAS;
+            HitInfo h;
+            bool bHit = false;
+            T.Closest(in, h, bHit, BHRT_HIT_BACK);
+            if (bHit && h.node >= 0) {
+                bool out;
+                Ray next = sh.HandleRayWhenRefractionRayOut(in, h, m.ior, out, m.refraction_glossiness);
+                if (out) { r = next; return true; }
+                return false;
+            }
+            return false;
+        }
+        if (rnd < 0.3f) return false; // Photon_AbsorbChance, MtlBlinn.cpp:27
+        float diffuseTheta = 0;
+        Vec3 diffuseRayDir = sh.GetSampleInSemiSphere(vN, diffuseTheta).GetNormalized();
+        (void)diffuseRayDir;
+        float p_diffuseTheta = M::Sin(2 * diffuseTheta);
+        float specularTheta = 0;
+        float cosvVvN = vN.Dot(vV);
+        Vec3 vR = 2 * cosvVvN * vN - vV;
+        Vec3 specRayDir = sh.GetSampleAlongLightDirection(vR, m.glossiness, specularTheta);
+        float p_specularTheta = M::Pow(M::Cos(specularTheta), m.glossiness);
+        float P_Diffuse = Shader<M>::GetK(m.diffuse) * p_diffuseTheta;
+        float P_sum = P_Diffuse + Shader<M>::GetK(m.specular) * p_specularTheta;
+        float p_Diff = (P_Diffuse / P_sum) * (1 - 0.3f) + 0.3f;
+        float p_Spec = (1 - p_Diff) * (1 - 0.3f) + 0.3f;
+        bool useSpecular = rnd >= p_Diff;
+        if (!useSpecular) return false;
+        Color ksf = Color(m.specular.color[0], m.specular.color[1], m.specular.color[2]) / p_Spec;
+        c = c * ksf;
+        r.dir = specRayDir;
+        r.p = hInfo.p + hInfo.N * O_BIAS;
+        return true;
+    }
+    // TraceCausticPhotonRay, Main.cpp:319-340 (tail recursion -> loop)
+    void TracePhoton(Ray ray, Color intensity)
+    {
+        bool first = true;
+        for (int guard = 0; guard < O_MAXLOOP; guard++) {
+            bool bHit = false;
+            HitInfo h;
+            T.Closest(ray, h, bHit, BHRT_HIT_FRONT);
+            if (!bHit) return;
+            int mi = S.nodes[h.node].material;
+            if (mi < 0) return; // null material: the reference dereferences null
+            const bhrt_material &m = S.materials[mi];
+            const bool photonSurface = Color(m.diffuse.color[0], m.diffuse.color[1], m.diffuse.color[2]).Gray() > 0; // materials.h:47
+            if (!first && photonSurface) AddPhoton(h.p, ray.dir.GetNormalized(), intensity);
+            if (m.kind != BHRT_MTL_BLINN) return; // MultiMtl has no caustic bounce (scene.h:298)
+            Ray nr = ray;
+            Color ni = intensity;
+            if (!BounceForCaustic(m, nr, ni, h)) return;
+            ray = nr;
+            intensity = ni;
+            first = false;
+        }
+    }
+    // PointLight::RandomPhoton, PointLight.cpp:20-34
+    Ray RandomPhoton(const bhrt_light &l)
+    {
+        float phi = (float)(rng.Rnd01() * 2 * O_PI);
+        float theta = M::Acos(MinF(1.f, MaxF(-1.f, 1 - 2 * rng.Rnd01())));
+        Vec3 axisZ(0, 0, 1), axisX(1, 0, 0), axisY(0, 1, 0);
+        Ray ray;
+        ray.dir = M::Sin(theta) * (axisX * M::Cos(phi) + axisY * M::Sin(phi)) + axisZ * M::Cos(theta);
+        ray.p = Vec3(l.vec[0], l.vec[1], l.vec[2]);
+        return ray;
+    }
+    // BuildCausticPhotonMap, Main.cpp:342-386
+    uint64_t Build(uint32_t seed, bool keyed)
+    {
+        std::vector<const bhrt_light *> pl;
+        for (uint32_t i = 0; i < S.H->n_lights; i++)
+            if (S.lights[i].type == BHRT_LIGHT_POINT) pl.push_back(&S.lights[i]); // the reference reinterpret_casts EVERY light (Q19)
+        if (pl.empty()) return 0;
+        auto key = [](const bhrt_light *l) { return Color(l->intensity[0], l->intensity[1], l->intensity[2]).Gray() * (int)l->size; };
+        std::sort(pl.begin(), pl.end(), [&](const bhrt_light *a, const bhrt_light *b) { return key(a) < key(b); });
+        float sum = 0;
+        for (auto *l : pl) sum += key(l);
+        uint64_t emitted = 0;
+        rng.keyed = false;
+        rng.key = bhrt_photon_key_sequential(seed);
+        rng.ctr = 0;
+        while (pm.numStored < maxPhotons) {
+            if (keyed) { rng.key = bhrt_photon_key(seed, emitted); rng.ctr = 0; }
+            float rnd = rng.Rnd01();
+            size_t i = 0;
+            while (rnd > Color(pl[i]->intensity[0], pl[i]->intensity[1], pl[i]->intensity[2]).Gray() * pl[i]->size / sum && i < pl.size() - 1) i++;
+            Ray ray = RandomPhoton(*pl[i]);
+            TracePhoton(ray, Color(pl[i]->intensity[0], pl[i]->intensity[1], pl[i]->intensity[2]));
+            emitted++;
+            if (emitted > (uint64_t)maxPhotons * 4096ull + (1ull << 24)) break; // no photon surface reachable: give up (the reference loops forever)
+        }
+        return emitted;
+    }
+};
+
 } // namespace
-extern "C" int oracle_photon_build(const void *, const oracle_opts *, uint32_t, void *, uint32_t *, uint64_t *) { g_err = "photon map: not restated yet"; return 99; }
-extern "C" int oracle_photon_attach(const void *, uint32_t) { g_err = "photon map: not restated yet"; return 99; }
-extern "C" int oracle_photon_gather(const float *, const float *, size_t, float, float *, float *) { g_err = "photon map: not restated yet"; return 99; }
+
+extern "C" int oracle_photon_build(const void *blob, const oracle_opts *opts, uint32_t max_photons, void *photons_out, uint32_t *n_stored, uint64_t *n_emitted)
+{
+    Scene S;
+    if (!S.Init(blob)) return 1;
+    PhotonMapView &pm = g_pm_storage;
+    pm.photons.assign((size_t)max_photons + 1, Photon());
+    memset(pm.photons.data(), 0, sizeof(Photon) * pm.photons.size());
+    pm.numStored = 0;
+    uint64_t emitted;
+    if (opts->math_mode == ORACLE_MATH_DEVICE) { PhotonTracer<MathDevice> t(S, pm, (int)max_photons); emitted = t.Build(opts->seed, opts->rng_mode == ORACLE_RNG_KEYED); }
+    else { PhotonTracer<MathLibm> t(S, pm, (int)max_photons); emitted = t.Build(opts->seed, opts->rng_mode == ORACLE_RNG_KEYED); }
+    if (pm.numStored > 0) {
+        const float scale = 1.f / pm.numStored; // ScalePhotonPowers, Main.cpp:380
+        for (int i = 1; i <= pm.numStored; i++) pm.photons[i].power *= scale;
+    }
+    pm.photons.resize((size_t)pm.numStored + 1);
+    pm.unbalanced.assign(pm.photons.begin() + 1, pm.photons.end());
+    PreparePhotonMap(pm);
+    if (photons_out && pm.numStored) memcpy(photons_out, &pm.photons[1], sizeof(Photon) * pm.numStored);
+    if (n_stored) *n_stored = (uint32_t)pm.numStored;
+    if (n_emitted) *n_emitted = emitted;
+    g_photon_map = &pm;
+    return 0;
+}
+
+extern "C" int oracle_photon_unbalanced(void *out)
+{
+    if (!out) return 1;
+    if (!g_pm_storage.unbalanced.empty()) memcpy(out, g_pm_storage.unbalanced.data(), sizeof(Photon) * g_pm_storage.unbalanced.size());
+    return 0;
+}
+
+extern "C" int oracle_photon_attach(const void *photons, uint32_t n)
+{
+    PhotonMapView &pm = g_pm_storage;
+    pm.photons.assign((size_t)n + 1, Photon());
+    memset(pm.photons.data(), 0, sizeof(Photon));
+    if (n) memcpy(&pm.photons[1], photons, sizeof(Photon) * n);
+    pm.numStored = (int)n;
+    pm.halfStored = pm.numStored / 2 - 1;
+    g_photon_map = n ? &pm : nullptr;
+    return 0;
+}
+
+extern "C" int oracle_photon_balance(const void *emitted, uint32_t n, void *balanced_out)
+{
+    PhotonMapView pm;
+    pm.photons.assign((size_t)n + 1, Photon());
+    memset(pm.photons.data(), 0, sizeof(Photon));
+    if (n) memcpy(&pm.photons[1], emitted, sizeof(Photon) * n);
+    pm.numStored = (int)n;
+    PreparePhotonMap(pm);
+    if (n) memcpy(balanced_out, &pm.photons[1], sizeof(Photon) * n);
+    return 0;
+}
+
+extern "C" int oracle_photon_gather(const float *p, const float *nrm, size_t cnt, float radius, float *irrad, float *dir)
+{
+    if (!g_photon_map) { g_err = "no photon map attached"; return 1; }
+    for (size_t i = 0; i < cnt; i++) {
+        Color c;
+        Vec3 d;
+        PhotonEstimate(g_photon_map, c, d, radius, Vec3(p[i * 3], p[i * 3 + 1], p[i * 3 + 2]), Vec3(nrm[i * 3], nrm[i * 3 + 1], nrm[i * 3 + 2]));
+        irrad[i * 3] = c.r; irrad[i * 3 + 1] = c.g; irrad[i * 3 + 2] = c.b;
+        dir[i * 3] = d.x; dir[i * 3 + 1] = d.y; dir[i * 3 + 2] = d.z;
+    }
+    return 0;
+}

@@ -67,7 +67,9 @@ int oracle_math_eval(int fn, int math_mode, const float *a, const float *b, size
 /* caustic photon map (Main.cpp:342-386, cyPhotonMap.h) — see bhrt_oracle.cpp */
 int oracle_photon_build(const void *blob, const oracle_opts *opts, uint32_t max_photons, void *photons_out /* 24 B each */,
                         uint32_t *n_stored, uint64_t *n_emitted);
-int oracle_photon_attach(const void *photons, uint32_t n); /* balanced (heap-order) array incl. slot 0 */
+int oracle_photon_unbalanced(void *out);                     /* the same photons in emission order (n_stored records) */
+int oracle_photon_attach(const void *photons, uint32_t n);  /* n balanced (heap-order) records, e.g. from the HIP path */
+int oracle_photon_balance(const void *emitted, uint32_t n, void *balanced_out); /* PrepareForIrradianceEstimation on n records */
 int oracle_photon_gather(const float *p, const float *nrm, size_t cnt, float radius, float *irrad, float *dir);
 
 const char *oracle_last_error(void);

@@ -250,12 +250,48 @@ static void DumpScene(const std::string &prefix)
     }
 }
 
+#ifdef USE_PhotonMap
+// BuildCausticPhotonMap (Main.cpp:342-386) with the photon budget as a run-time value (the reference's
+// MAX_CausticPhotonCount is an unguarded #define) and without the .dat write.  Everything it calls is the reference's own
+// code: ComparePointLight, PointLight::GetProbability/RandomPhoton/GetPhotonIntensity, TraceCausticPhotonRay,
+// PhotonMap::Resize/NumPhotons/ScalePhotonPowers/PrepareForIrradianceEstimation.
+static unsigned long long g_emitted = 0;
+static std::vector<unsigned char> g_unbalanced;
+static bool BuildCausticPhotonMapN(int maxPhotons)
+{
+    causticPhotonMap = new PhotonMap();
+    causticPhotonMap->Resize(maxPhotons);
+    memset((void *)&causticPhotonMap->photons[0], 0, sizeof(cyPhotonMap::Photon) * (maxPhotons + 1)); // defined bytes for slot 0 / plane bits
+    std::vector<PointLight *> pointLightList;
+    for (auto it = lights.begin(); it != lights.end(); ++it)
+        if (PointLight *ptr = reinterpret_cast<PointLight *>(*it)) pointLightList.push_back(ptr);
+    if (pointLightList.size() == 0) return false;
+    sort(pointLightList.begin(), pointLightList.end(), ComparePointLight);
+    float sumOfPointLight = 0;
+    for (int i = 0; i < pointLightList.size(); ++i) sumOfPointLight += pointLightList[i]->GetIntensity() * pointLightList[i]->GetSize();
+    while (causticPhotonMap->NumPhotons() < maxPhotons) {
+        float rnd = Rnd01();
+        int i = 0;
+        while (rnd > pointLightList[i]->GetProbability(sumOfPointLight) && i < pointLightList.size() - 1) i++;
+        PointLight *thisLight = pointLightList[i];
+        Ray ray = thisLight->RandomPhoton();
+        Color bounceIntensity = thisLight->GetPhotonIntensity();
+        TraceCausticPhotonRay(ray, bounceIntensity, true);
+        g_emitted++;
+    }
+    causticPhotonMap->ScalePhotonPowers(1.f / causticPhotonMap->NumPhotons());
+    g_unbalanced.assign((unsigned char *)causticPhotonMap->GetPhotons(), (unsigned char *)causticPhotonMap->GetPhotons() + sizeof(cyPhotonMap::Photon) * maxPhotons);
+    causticPhotonMap->PrepareForIrradianceEstimation();
+    return true;
+}
+#endif
+
 static void usage()
 {
     fprintf(stderr,
             "usage: ref_harness <scene.xml> <out_prefix> [--spp N] [--gi G] [--bounce B] [--seed S]\n"
             "                   [--region x0 y0 x1 y1] [--rays file] [--shadow file] cmd...\n"
-            "  cmds: dump primary rays shadow render\n");
+            "  cmds: dump primary rays shadow render  (photon build only: photons gather; --photons N --gather file)\n");
     exit(2);
 }
 
@@ -267,7 +303,8 @@ int main(int argc, char **argv)
     int spp = 1, gi = GIBounceCount, bounce = INTERNAL_REFLECTION_BOUNCE;
     uint32_t seed = 0;
     int rx0 = 0, ry0 = 0, rx1 = -1, ry1 = -1;
-    std::string raysFile, shadowFile;
+    std::string raysFile, shadowFile, gatherFile;
+    int nPhotons = 10000;
     std::vector<std::string> cmds;
     for (int a = 3; a < argc; a++) {
         std::string s = argv[a];
@@ -277,6 +314,8 @@ int main(int argc, char **argv)
         else if (s == "--seed") seed = (uint32_t)strtoul(argv[++a], 0, 10);
         else if (s == "--region") { rx0 = atoi(argv[a + 1]); ry0 = atoi(argv[a + 2]); rx1 = atoi(argv[a + 3]); ry1 = atoi(argv[a + 4]); a += 4; }
         else if (s == "--rays") raysFile = argv[++a];
+        else if (s == "--photons") nPhotons = atoi(argv[++a]);
+        else if (s == "--gather") gatherFile = argv[++a];
         else if (s == "--shadow") shadowFile = argv[++a];
         else cmds.push_back(s);
     }
@@ -331,6 +370,29 @@ int main(int argc, char **argv)
                 out.push_back(Probe::S(ray, in[r + 6]));
             }
             WriteFile(prefix + ".shadow_f32", out);
+#ifdef USE_PhotonMap
+        } else if (cmd == "photons") {
+            // one sequential stream for the whole emission loop, like the reference's global rand()
+            g_key = bhrt_sample_key(seed, 0xFFFFFFFFu, 0x50484F54u);
+            g_ctr = 0;
+            if (!BuildCausticPhotonMapN(nPhotons)) { fprintf(stderr, "no point light\n"); return 3; }
+            std::vector<unsigned char> bal((unsigned char *)causticPhotonMap->GetPhotons(), (unsigned char *)causticPhotonMap->GetPhotons() + sizeof(cyPhotonMap::Photon) * nPhotons);
+            WriteFile(prefix + ".photons_emitted", g_unbalanced);
+            WriteFile(prefix + ".photons_balanced", bal);
+            std::vector<unsigned long long> meta = {(unsigned long long)causticPhotonMap->NumPhotons(), g_emitted, (unsigned long long)g_ctr, (unsigned long long)(long long)causticPhotonMap->halfStoredPhotons};
+            WriteFile(prefix + ".photons_meta", meta);
+        } else if (cmd == "gather") {
+            std::vector<float> in = ReadFile<float>(gatherFile); // N x 6: p, normal
+            std::vector<float> out;
+            for (size_t r = 0; r + 5 < in.size(); r += 6) {
+                Vec3f pos(in[r], in[r + 1], in[r + 2]), nrm(in[r + 3], in[r + 4], in[r + 5]), dir;
+                Color irr;
+                causticPhotonMap->EstimateIrradiance<1000>(irr, dir, 0.5, pos, &nrm); // as called at MtlBlinn.cpp:334
+                out.push_back(irr.r); out.push_back(irr.g); out.push_back(irr.b);
+                out.push_back(dir.x); out.push_back(dir.y); out.push_back(dir.z);
+            }
+            WriteFile(prefix + ".gather_f32", out);
+#endif
         } else if (cmd == "render") {
             // per-sample body of PathTracing (Main.cpp:145-168) with rand() reset per (pixel, sample)
             const int rw = rx1 - rx0, rh = ry1 - ry0;

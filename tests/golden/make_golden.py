@@ -24,6 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SCENES = os.path.join(ROOT, "tests", "scenes")
 HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+HARNESS_PM = os.path.join(ROOT, "oracle", "_ref", "ref_harness_pm")  # reference built with -DUSE_PhotonMap
 
 # scene file, render region, spp, gi
 CASES = {
@@ -109,7 +110,39 @@ def main():
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
         print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {int((pi[..., 0] >= 0).sum())}/{W * H} primary hits")
+    photon_case(tmp)
     subprocess.run(["rm", "-rf", tmp])
+
+
+def photon_case(tmp):
+    """Caustic photon map (Main.cpp:342-386, cyPhotonMap.h): the -DUSE_PhotonMap build of the reference emits, balances,
+    gathers and renders; rand() interposed by ONE sequential stream for the whole emission loop."""
+    name, xml, n_photons, region, spp, gi = "c5_caustics_photon", "c5_caustics.xml", 6000, (110, 160, 158, 196), 2, 2
+    pre = os.path.join(tmp, name)
+    rng = np.random.RandomState(5)
+    q = np.concatenate([rng.uniform([-14, -20, 0.0], [14, 10, 0.0], (150, 3)), np.tile([0, 0, 1.0], (150, 1))], 1)
+    q2 = np.concatenate([rng.uniform([-11, -9, 0.0], [-5, -3, 0.0], (250, 3)), np.tile([0, 0, 1.0], (250, 1))], 1)  # under the glass sphere
+    q3 = np.concatenate([rng.uniform([-9, -7, 0.0], [-7, -5, 0.0], (100, 3)), np.tile([0, 0, -1.0], (100, 1))], 1)  # wrong-side normals
+    q = np.concatenate([q, q2, q3]).astype(np.float32)
+    q.tofile(pre + ".q")
+    subprocess.run([HARNESS_PM, os.path.join(SCENES, xml), pre, "--photons", str(n_photons), "--gather", pre + ".q", "--spp", str(spp), "--gi", str(gi),
+                    "--region", *map(str, region), "photons", "gather", "render"], cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    meta = np.fromfile(pre + ".photons_meta", np.uint64)
+    npx = (region[2] - region[0]) * (region[3] - region[1])
+    out = {
+        "n_photons": n_photons, "stored": int(meta[0]), "emitted": int(meta[1]), "draws": int(meta[2]), "half": int(np.int64(meta[3])),
+        # byte 19 (planeAndDirZ) has uninitialised low bits in the reference: bit 3 (sign of dirZ) always valid,
+        # bits 0-1 (split plane) valid for internal nodes (index < half)
+        "photons_emitted": np.fromfile(pre + ".photons_emitted", np.uint8).reshape(-1, 24),
+        "photons_balanced": np.fromfile(pre + ".photons_balanced", np.uint8).reshape(-1, 24),
+        "gather_q": q, "gather_out": np.fromfile(pre + ".gather_f32", np.float32).reshape(-1, 6),
+        "render_region": np.array(region, np.int32), "render_spp": spp, "render_gi": gi,
+        "render_samples": np.fromfile(pre + ".samples_f32", np.float32).reshape(npx, spp, 3),
+    }
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {out['stored']} photons from {out['emitted']} emissions, "
+          f"{int((out['gather_out'][:, :3].sum(1) > 0).sum())}/{len(q)} queries lit")
 
 
 if __name__ == "__main__":

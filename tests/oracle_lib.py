@@ -78,9 +78,9 @@ def trace_shadow(blob: bytes, origins, dirs, tmax):
 
 
 def render(blob: bytes, width, height, spp, gi=3, bounces=16, seed=0, rng=RNG_KEYED, math=MATH_DEVICE, jitter=1,
-           region=None, threads=8, want_samples=True):
+           region=None, threads=8, want_samples=True, photon=0):
     x0, y0, x1, y1 = region if region else (0, 0, width, height)
-    o = OracleOpts(spp, gi, bounces, seed, rng, math, jitter, x0, y0, x1, y1, threads, 0)
+    o = OracleOpts(spp, gi, bounces, seed, rng, math, jitter, x0, y0, x1, y1, threads, photon)
     npx = (x1 - x0) * (y1 - y0)
     samples = np.zeros((npx, spp, 3), np.float32) if want_samples else None
     rad = np.zeros((npx, 3), np.float32)
@@ -90,6 +90,39 @@ def render(blob: bytes, width, height, spp, gi=3, bounces=16, seed=0, rng=RNG_KE
                                C.byref(st)))
     return {"samples": samples, "radiance": rad.reshape(y1 - y0, x1 - x0, 3), "rgb8": rgb.reshape(y1 - y0, x1 - x0, 3),
             "stats": st}
+
+
+def photon_build(blob: bytes, max_photons, seed=0, rng=RNG_KEYED, math=MATH_DEVICE):
+    """BuildCausticPhotonMap (Main.cpp:342-386); the map stays attached for photon_gather / render(photon=1).
+    Returns (balanced (n,24) uint8, emission-order (n,24) uint8, n_emitted)."""
+    o = OracleOpts(1, 3, 16, seed, rng, math, 1, 0, 0, 0, 0, 1, 0)
+    out = np.zeros((max_photons, 24), np.uint8)
+    ns, ne = C.c_uint32(), C.c_uint64()
+    _check(lib().oracle_photon_build(C.c_char_p(blob), C.byref(o), int(max_photons), _p(out), C.byref(ns), C.byref(ne)))
+    unb = np.zeros((ns.value, 24), np.uint8)
+    _check(lib().oracle_photon_unbalanced(_p(unb)))
+    return out[:ns.value].copy(), unb, ne.value
+
+
+def photon_attach(balanced):
+    a = np.ascontiguousarray(balanced, np.uint8)
+    _check(lib().oracle_photon_attach(_p(a), a.shape[0]))
+
+
+def photon_balance(emitted):
+    a = np.ascontiguousarray(emitted, np.uint8)
+    out = np.zeros_like(a)
+    _check(lib().oracle_photon_balance(_p(a), a.shape[0], _p(out)))
+    return out
+
+
+def photon_gather(p, nrm, radius=0.5):
+    p = np.ascontiguousarray(p, np.float32)
+    nrm = np.ascontiguousarray(nrm, np.float32)
+    irr = np.zeros_like(p)
+    d = np.zeros_like(p)
+    _check(lib().oracle_photon_gather(_p(p), _p(nrm), C.c_size_t(p.shape[0]), C.c_float(radius), _p(irr), _p(d)))
+    return irr, d
 
 
 def bvh_build(v, f, max_per_leaf=4):

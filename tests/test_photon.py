@@ -1,0 +1,110 @@
+"""Caustic photon map: Main.cpp:319-386, DataStructure/cyPhotonMap.h,
+MtlBlinn.cpp:203-303,329-342.
+
+CPU: the oracle against the golden vectors of the reference built with -DUSE_PhotonMap (tests/golden/
+c5_caustics_photon.npz): emitted photons, kd-balanced array, k-NN irradiance estimates, radiance with the
+caustic term — all bit-exact.  GPU: the HIP emission / gather kernels against the oracle in keyed + device-math mode."""
+import numpy as np
+import pytest
+
+from conftest import same_bits
+
+
+def check_photon_bytes(mine, ref, half=None):
+    """Reference photons carry uninitialised bits in byte 19 (planeAndDirZ): bit 3 (dirZ sign) is always set
+    deliberately, bits 0-1 (split plane) only for internal kd nodes."""
+    m = np.ones(24, bool)
+    m[19] = False
+    assert np.array_equal(mine[:, m], ref[:, m])
+    assert np.array_equal(mine[:, 19] & 8, ref[:, 19] & 8)
+    if half is not None:
+        internal = np.arange(1, len(ref) + 1) < half
+        assert np.array_equal(mine[internal, 19] & 3, ref[internal, 19] & 3)
+
+
+def test_oracle_photon_map_vs_reference_golden(load_scene, golden, O):
+    g = golden("c5_caustics_photon")
+    sc = load_scene("c5_caustics")
+    bal, emitted, n_emit = O.photon_build(sc.flat_bytes(), int(g["n_photons"]), rng=O.RNG_SEQUENTIAL, math=O.MATH_LIBM)
+    assert len(bal) == int(g["stored"]) and n_emit == int(g["emitted"])
+    check_photon_bytes(emitted, g["photons_emitted"])                      # emission, bounce rules, 24-byte packing
+    check_photon_bytes(bal, g["photons_balanced"], int(g["half"]))         # left-balanced kd-tree in heap order
+    q = g["gather_q"]
+    irr, d = O.photon_gather(q[:, :3], q[:, 3:], 0.5)                      # EstimateIrradiance<1000>(..., 0.5, p, &N)
+    assert same_bits(np.concatenate([irr, d], 1), g["gather_out"])
+    lit = g["gather_out"][:, :3].sum(1) > 0
+    assert 100 < lit.sum() < len(q)
+    region = tuple(int(x) for x in g["render_region"])
+    r = O.render(sc.flat_bytes(), sc.width, sc.height, int(g["render_spp"]), gi=int(g["render_gi"]), rng=O.RNG_SEQUENTIAL,
+                 math=O.MATH_LIBM, region=region, threads=4, photon=1)
+    assert same_bits(r["samples"], g["render_samples"])                    # Shade() with the caustic term (MtlBlinn.cpp:329-342)
+
+
+def test_photon_record_layout_and_direction_quirk(load_scene, O):
+    sc = load_scene("c5_caustics")
+    bal, emitted, _ = O.photon_build(sc.flat_bytes(), 500)
+    assert bal.dtype == np.uint8 and bal.shape == (500, 24)
+    rec = np.dtype([("pos", "<f4", 3), ("power", "<f4"), ("color", "u1", 3), ("plane", "u1"), ("dx", "<i2"), ("dy", "<i2")])
+    p = emitted.view(rec).reshape(-1)
+    assert np.all(np.isfinite(p["pos"])) and np.all(p["power"] > 0)
+    assert np.allclose(p["power"].astype(np.float64).sum() * 0 + p["color"].max(axis=1), 255)   # SetPower: max channel -> 255
+    # powers were scaled by 1/N (ScalePhotonPowers, Main.cpp:380): total flux is O(light intensity), not O(N * intensity)
+    assert p["power"].sum() < 1000
+    # balancing is a permutation
+    assert sorted(map(bytes, emitted[:, :19])) == sorted(map(bytes, bal[:, :19]))
+    assert np.array_equal(O.photon_balance(emitted), bal)
+
+
+def test_heap_mode_more_than_1000_candidates(load_scene, O):
+    """> MAX_PhotonCountInArea photons inside the radius: the estimate switches to the max-heap with a shrinking
+    radius (cyPhotonMap.h:458-495); the result must not depend on threads/calls."""
+    sc = load_scene("c5_caustics")
+    O.photon_build(sc.flat_bytes(), 30000)
+    rng = np.random.RandomState(1)
+    p = rng.uniform([-9.0, -7.0, 0.0], [-7.0, -5.0, 0.0], (64, 3)).astype(np.float32)
+    n = np.tile(np.float32([0, 0, 1]), (64, 1))
+    big, _ = O.photon_gather(p, n, 3.0)      # radius 3: thousands of candidates under the glass sphere
+    small, _ = O.photon_gather(p, n, 0.5)
+    assert (big.sum(1) > 0).all()
+    again, _ = O.photon_gather(p, n, 3.0)
+    assert same_bits(big, again)
+    assert not same_bits(big, small)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_gpu_photon_map_vs_oracle(B, load_scene, O):
+    if B.device_count() < 1:
+        pytest.fail("no HIP device")
+    sc = load_scene("c5_caustics")
+    N = 20000
+    opts = B.default_opts(seed=3)
+    n = sc.photon_build(opts, N)
+    bal, emitted, n_emit = O.photon_build(sc.flat_bytes(), N, seed=3)        # keyed + device math: same streams as the kernels
+    assert n == len(bal) == N
+    got = sc.photon_get()
+    assert np.array_equal(got, bal)                                         # emission + compaction + balance: every byte
+    # k-NN irradiance estimate, normal and heap mode, wrong-side normals
+    rng = np.random.RandomState(9)
+    p = np.concatenate([rng.uniform([-14, -20, 0.0], [14, 10, 0.0], (300, 3)), rng.uniform([-11, -9, 0.0], [-5, -3, 0.0], (500, 3))]).astype(np.float32)
+    nr = np.tile(np.float32([0, 0, 1]), (len(p), 1))
+    nr[::9] = [0, 0, -1]
+    for radius in (0.5, 2.5):
+        gi, gd = sc.photon_gather(p, nr, radius)
+        oi, od = O.photon_gather(p, nr, radius)
+        assert same_bits(gi, oi) and same_bits(gd, od)
+    assert (oi.sum(1) > 0).sum() > 300
+    # radiance with the caustic term
+    region = (90, 150, 200, 215)
+    ropts = B.default_opts(spp=2, gi_bounces=2, seed=3, photon_map=1)
+    gs, st = sc.render_samples(ropts, *region)
+    ro = O.render(sc.flat_bytes(), sc.width, sc.height, 2, gi=2, seed=3, region=region, photon=1)
+    assert np.nanmax(np.abs(gs - ro["samples"])) <= 1e-4
+    assert same_bits(gs, ro["samples"])
+    off, _ = sc.render_samples(B.default_opts(spp=2, gi_bounces=2, seed=3), *region)
+    assert not same_bits(gs, off)                                           # the caustic actually contributes here
+    # export = the reference's .dat (24-byte records, Main.cpp:383-385)
+    import os, tempfile
+    path = os.path.join(tempfile.mkdtemp(), "causticPhotonMap.dat")
+    sc.photon_export(path)
+    assert np.array_equal(np.fromfile(path, np.uint8).reshape(-1, 24), bal)
