@@ -79,7 +79,7 @@ __device__ inline void hit_attrs(const DevScene &S, V3 o, V3 d, float t, int nod
         const bhrt_mesh &m = S.meshes[nd.mesh];
         const bhrt_tri &tr = ((const bhrt_tri *)(S.blob + m.off_tris))[prim];
         V3 v0 = ld3(tr.v0), v1 = ld3(tr.v1), v2 = ld3(tr.v2);
-        V3 vN = cross(v1 - v0, v2 - v0);
+        V3 vN = ld3(tr.vN);
         V3 vX = lp + t * ld;
         float a0, a1, a2;
         tri_areas(v0, v1, v2, vN, vX, a0, a1, a2);

@@ -74,6 +74,41 @@ __device__ inline bool box_hit(const float *b, V3 o, V3 d, float t_max, float &t
     return false;
 }
 
+// The same slab test for many boxes along ONE ray: the six IEEE float divisions per box become
+// float(double(a) * rd) with rd = 1.0 / double(d) computed once per ray and axis.  This is bit-identical to the
+// float division a / d: the quotient of two binary32 numbers is never closer than 2^-49 (relative) to a rounding
+// boundary (midpoint) of binary32, while double(a)*rd differs from a/d by at most 2^-52 (relative), so both round
+// to the same float.  The argument needs a normal, finite quotient; anything else takes the plain division.
+struct RayRcp {
+    double rx, ry, rz;
+};
+__device__ inline RayRcp ray_rcp(V3 d)
+{
+    RayRcp r;
+    r.rx = 1.0 / (double)d.x; r.ry = 1.0 / (double)d.y; r.rz = 1.0 / (double)d.z;
+    return r;
+}
+__device__ inline float div_shared(float a, float d, double rd)
+{
+    const float q = (float)((double)a * rd);
+    const float aq = fabsf(q);
+    if (aq > 1e-30f && aq < 1e30f) return q; // normal range (also excludes NaN / inf / zero results)
+    return a / d;
+}
+__device__ inline bool box_hit_rcp(const float *b, V3 o, V3 d, const RayRcp &r, float t_max, float &t_min)
+{
+    float tz1 = (d.z != 0) ? div_shared(b[2] - o.z, d.z, r.rz) : BHRT_BIGFLOAT;
+    float tz2 = (d.z != 0) ? div_shared(b[5] - o.z, d.z, r.rz) : -BHRT_BIGFLOAT;
+    float ty1 = (d.y != 0) ? div_shared(b[1] - o.y, d.y, r.ry) : BHRT_BIGFLOAT;
+    float ty2 = (d.y != 0) ? div_shared(b[4] - o.y, d.y, r.ry) : -BHRT_BIGFLOAT;
+    float tx1 = (d.x != 0) ? div_shared(b[0] - o.x, d.x, r.rx) : BHRT_BIGFLOAT;
+    float tx2 = (d.x != 0) ? div_shared(b[3] - o.x, d.x, r.rx) : -BHRT_BIGFLOAT;
+    float tMin = fmax_cy(fmax_cy(fmin_cy(tx1, tx2), fmin_cy(ty1, ty2)), fmin_cy(tz1, tz2));
+    float tMax = fmin_cy(fmin_cy(fmax_cy(tx1, tx2), fmax_cy(ty1, ty2)), fmax_cy(tz1, tz2));
+    if (tMin <= tMax && tMin < t_max) { t_min = tMin; return true; }
+    return false;
+}
+
 // barycentric part of IntersectTriangle (TriObj.cpp:105-168), shared with the attribute recomputation
 __device__ inline bool tri_areas(V3 v0, V3 v1, V3 v2, V3 vN, V3 vX, float &a0, float &a1, float &a2)
 {
@@ -91,20 +126,21 @@ __device__ inline bool tri_areas(V3 v0, V3 v1, V3 v2, V3 vN, V3 vX, float &a0, f
     return true;
 }
 
-// TriObj::IntersectTriangle (TriObj.cpp:68-189) up to the accept decision; dlen = ray.dir.Length()
+// TriObj::IntersectTriangle (TriObj.cpp:68-189) up to the accept decision; dlen = ray.dir.Length();
+// vN, |vN| and vN.v0 come precomputed with the triangle (same float operations as TriObj.cpp:79,85,89)
 __device__ inline bool tri_hit(const bhrt_tri &tr, V3 o, V3 d, float dlen, int side, float t_cur, float &t_out, int &front_out)
 {
-    V3 v0 = ld3(tr.v0), v1 = ld3(tr.v1), v2 = ld3(tr.v2);
-    V3 vN = cross(v1 - v0, v2 - v0);
+    V3 vN = ld3(tr.vN);
     float t_divisor = dot(vN, d);
     if (t_divisor == 0) return false;
-    float perp = t_divisor / (length(vN) * dlen);
+    float perp = t_divisor / (tr.vN_len * dlen);
     if (perp > -BHRT_PERP && perp < BHRT_PERP) return false;
-    float t = (dot(vN, v0) - dot(vN, o)) / t_divisor;
+    float t = (tr.vN_dot_v0 - dot(vN, o)) / t_divisor;
     if (t <= 0 || t > t_cur) return false;
     bool hitFront = t_divisor < 0;
     if (!hitFront && side == BHRT_HIT_FRONT) return false;
     else if (hitFront && side == BHRT_HIT_BACK) return false;
+    V3 v0 = ld3(tr.v0), v1 = ld3(tr.v1), v2 = ld3(tr.v2);
     V3 vX = o + t * d;
     float a0, a1, a2;
     if (!tri_areas(v0, v1, v2, vN, vX, a0, a1, a2)) return false;
@@ -142,7 +178,8 @@ __device__ inline MeshRef mesh_ref(const DevScene &S, int mi)
 __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront)
 {
     float tm;
-    if (!box_hit(M.bvh[1].b, o, d, ht, tm)) return false;
+    const RayRcp rr = ray_rcp(d);
+    if (!box_hit_rcp(M.bvh[1].b, o, d, rr, ht, tm)) return false;
     const float dlen = length(d);
     uint32_t cur = 1;
     int depth = 0;
@@ -165,8 +202,8 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
             } else {
                 const uint32_t c1 = data & 0x7fffffffu;
                 float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
-                bool b1 = box_hit(M.bvh[c1].b, o, d, ht, tmin1);
-                bool b2 = box_hit(M.bvh[c1 + 1].b, o, d, ht, tmin2);
+                bool b1 = box_hit_rcp(M.bvh[c1].b, o, d, rr, ht, tmin1);
+                bool b2 = box_hit_rcp(M.bvh[c1 + 1].b, o, d, rr, ht, tmin2);
                 if (!b1 && !b2) { r = false; desc = false; }
                 else {
                     depth++;
@@ -184,7 +221,7 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
                 if (r) {
                     nearHit |= bit;
                     float tmf;
-                    if (box_hit(M.bvh[sib].b, o, d, ht, tmf)) { inFar |= bit; cur = sib; desc = true; }
+                    if (box_hit_rcp(M.bvh[sib].b, o, d, rr, ht, tmf)) { inFar |= bit; cur = sib; desc = true; }
                     else { cur = M.bvh[cur].parent; depth--; /* r stays true */ }
                 } else {
                     inFar |= bit;
@@ -207,7 +244,8 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
 __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
 {
     float tm;
-    if (!box_hit(M.bvh[1].b, o, d, BHRT_BIGFLOAT, tm)) return false;
+    const RayRcp rr = ray_rcp(d);
+    if (!box_hit_rcp(M.bvh[1].b, o, d, rr, BHRT_BIGFLOAT, tm)) return false;
     const float dlen = length(d);
     uint32_t cur = 1;
     int depth = 0;
@@ -229,8 +267,8 @@ __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
             } else {
                 const uint32_t c1 = data & 0x7fffffffu;
                 float t1, t2;
-                bool b1 = box_hit(M.bvh[c1].b, o, d, BHRT_BIGFLOAT, t1);
-                bool b2 = box_hit(M.bvh[c1 + 1].b, o, d, BHRT_BIGFLOAT, t2);
+                bool b1 = box_hit_rcp(M.bvh[c1].b, o, d, rr, BHRT_BIGFLOAT, t1);
+                bool b2 = box_hit_rcp(M.bvh[c1 + 1].b, o, d, rr, BHRT_BIGFLOAT, t2);
                 if (!b1 && !b2) desc = false;
                 else { depth++; cur = c1; }
             }

@@ -1008,6 +1008,13 @@ int LoadSceneXml(const char *path, FlatScene &out, std::string &err)
             memcpy(tris[f].v0, &m.v[m.f[f * 3] * 3], 12);
             memcpy(tris[f].v1, &m.v[m.f[f * 3 + 1] * 3], 12);
             memcpy(tris[f].v2, &m.v[m.f[f * 3 + 2] * 3], 12);
+            // TriObj.cpp:79,85,89: the same float operations the reference performs per intersection test
+            const V3 a = v3(tris[f].v0[0], tris[f].v0[1], tris[f].v0[2]), b = v3(tris[f].v1[0], tris[f].v1[1], tris[f].v1[2]),
+                     c = v3(tris[f].v2[0], tris[f].v2[1], tris[f].v2[2]);
+            const V3 vN = cross(b - a, c - a);
+            tris[f].vN[0] = vN.x; tris[f].vN[1] = vN.y; tris[f].vN[2] = vN.z;
+            tris[f].vN_len = length(vN);
+            tris[f].vN_dot_v0 = dot(vN, a);
         }
         o.off_tris = W.Append(tris.data(), tris.size() * sizeof(bhrt_tri));
         memcpy(o.bound_min, m.bound_min, 12);

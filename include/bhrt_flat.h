@@ -20,7 +20,7 @@
 #include <stdint.h>
 
 #define BHRT_FLAT_MAGIC 0x54524842u /* "BHRT" */
-#define BHRT_FLAT_VERSION 3u
+#define BHRT_FLAT_VERSION 4u
 #define BHRT_MAX_NODE_DEPTH 8 /* scene-graph depth below the root the kernels support */
 #define BHRT_BIGFLOAT 1.0e30f  /* Scenes/scene.h:38 */
 
@@ -59,10 +59,15 @@ typedef struct bhrt_bvh_node {
     uint32_t parent;
 } bhrt_bvh_node; /* 32 B */
 
-/* Pre-gathered triangle (device-friendly copy of v[f[i].v[0..2]]); 48 B */
+/* Pre-gathered triangle (device-friendly copy of v[f[i].v[0..2]]) plus the per-face constants that
+ * TriObj::IntersectTriangle recomputes on every test (TriObj.cpp:79-89): vN = (v1-v0)x(v2-v0), |vN| and vN.v0 —
+ * computed on the host with the same float operations, so the bits equal the reference's. 64 B */
 typedef struct bhrt_tri {
     float v0[3], v1[3], v2[3];
-    float pad[3];
+    float vN[3];
+    float vN_len;
+    float vN_dot_v0;
+    float pad[2];
 } bhrt_tri;
 
 typedef struct bhrt_mesh {
