@@ -185,47 +185,59 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
     int depth = 0;
     uint64_t inFar = 0, nearHit = 0;
     bool desc = true, r = false, any = false;
+    uint32_t data = M.bvh[1].data;
+    // "while-while" form of the state machine: the lanes of a wave run the three phases together (descend through
+    // inner nodes / test a leaf / climb), so a wave executes max-per-phase work instead of the union of all
+    // three bodies on every step.
     while (true) {
-        if (desc) {
-            const uint32_t data = M.bvh[cur].data;
-            if (data & 0x80000000u) {
-                const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
-                r = false;
-                for (uint32_t i = 0; i < count; i++) {
-                    const uint32_t face = M.elems[off + i];
-                    float t;
-                    int fr;
-                    if (tri_hit(M.tris[face], o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)face; hfront = fr; r = true; }
-                }
-                any |= r;
-                desc = false;
-            } else {
-                const uint32_t c1 = data & 0x7fffffffu;
-                float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
-                bool b1 = box_hit_rcp(M.bvh[c1].b, o, d, rr, ht, tmin1);
-                bool b2 = box_hit_rcp(M.bvh[c1 + 1].b, o, d, rr, ht, tmin2);
-                if (!b1 && !b2) { r = false; desc = false; }
-                else {
-                    depth++;
-                    const uint64_t bit = 1ull << (depth - 1);
-                    inFar &= ~bit;
-                    nearHit &= ~bit;
-                    cur = (tmin1 < tmin2) ? c1 : c1 + 1;
-                }
+        // ---- phase 1: descend through inner nodes
+        while (desc && !(data & 0x80000000u)) {
+            const uint32_t c1 = data & 0x7fffffffu;
+            float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
+            const bhrt_bvh_node &n1 = M.bvh[c1], &n2 = M.bvh[c1 + 1];
+            const uint32_t d1 = n1.data, d2 = n2.data;
+            bool b1 = box_hit_rcp(n1.b, o, d, rr, ht, tmin1);
+            bool b2 = box_hit_rcp(n2.b, o, d, rr, ht, tmin2);
+            if (!b1 && !b2) { r = false; desc = false; }
+            else {
+                depth++;
+                const uint64_t bit = 1ull << (depth - 1);
+                inFar &= ~bit;
+                nearHit &= ~bit;
+                const bool first1 = tmin1 < tmin2;
+                cur = first1 ? c1 : c1 + 1;
+                data = first1 ? d1 : d2;
             }
-        } else {
-            if (depth == 0) break;
+        }
+        // ---- phase 2: leaf
+        if (desc) {
+            const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
+            r = false;
+            for (uint32_t i = 0; i < count; i++) {
+                const uint32_t face = M.elems[off + i];
+                float t;
+                int fr;
+                if (tri_hit(M.tris[face], o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)face; hfront = fr; r = true; }
+            }
+            any |= r;
+            desc = false;
+        }
+        // ---- phase 3: climb until a sibling has to be visited or the root returns
+        while (!desc && depth > 0) {
             const uint64_t bit = 1ull << (depth - 1);
             const uint32_t sib = cur ^ 1u;
             if (!(inFar & bit)) {
                 if (r) {
                     nearHit |= bit;
                     float tmf;
-                    if (box_hit_rcp(M.bvh[sib].b, o, d, rr, ht, tmf)) { inFar |= bit; cur = sib; desc = true; }
+                    const bhrt_bvh_node &ns = M.bvh[sib];
+                    const uint32_t ds = ns.data;
+                    if (box_hit_rcp(ns.b, o, d, rr, ht, tmf)) { inFar |= bit; cur = sib; data = ds; desc = true; }
                     else { cur = M.bvh[cur].parent; depth--; /* r stays true */ }
                 } else {
                     inFar |= bit;
                     cur = sib;
+                    data = M.bvh[sib].data;
                     desc = true;
                 }
             } else {
@@ -234,6 +246,7 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
                 depth--;
             }
         }
+        if (!desc) break; // depth == 0: the root call returned
     }
     return any;
 }
