@@ -6,10 +6,10 @@
 // GPU's ocml do not round identically, and one differing ulp in a sampled direction changes which
 // object a secondary ray hits.  To keep the HIP path and the CPU oracle bit-comparable, both
 // evaluate these functions with THIS header in "device math" mode: every function is built from
-// IEEE-754 double + - * / and exact bit manipulation only, so host (x86-64 SSE2) and device
+// IEEE-754 float/double + - * / sqrt and exact bit manipulation only, so host (x86-64 SSE2) and device
 // (gfx950) produce identical bits when compiled with -ffp-contract=off.  Results are within
-// about 1 ulp (float) of the correctly rounded value, i.e. as close to libm as libm is to itself
-// across platforms; the oracle's libm mode (pinned against the compiled reference) and its
+// 1-3 ulp (float) of the correctly rounded value (trigonometry in single precision, pow through a
+// double-precision log/exp), i.e. the accuracy class of libm's own float functions; the oracle's libm mode (pinned against the compiled reference) and its
 // device-math mode are compared statistically in tests/.
 #pragma once
 #include <stdint.h>
@@ -43,50 +43,11 @@ BHRT_DM double rint_small(double x)
 // 2^k for -1022 <= k <= 1023
 BHRT_DM double pow2i(int k) { return bitsd((uint64_t)(k + 1023) << 52); }
 
-// sin and cos of a double argument of moderate size (|x| < ~1e5): Cody-Waite reduction by pi/2
-BHRT_DM void sincos_d(double x, double *s, double *c)
-{
-    const double two_over_pi = 0.63661977236758134308;
-    const double pio2_hi = 1.57079632673412561417e+00; // 33 bits of pi/2
-    const double pio2_lo = 6.07710050650619224932e-11; // pi/2 - pio2_hi
-    double kd = rint_small(x * two_over_pi);
-    double r = (x - kd * pio2_hi) - kd * pio2_lo;
-    long long k = (long long)kd;
-    double r2 = r * r;
-    // Taylor polynomials on |r| <= pi/4 (error < 1e-16 relative to 1)
-    double ps = r2 * (-1.0 / 6 + r2 * (1.0 / 120 + r2 * (-1.0 / 5040 + r2 * (1.0 / 362880 + r2 * (-1.0 / 39916800 + r2 * (1.0 / 6227020800.0 + r2 * (-1.0 / 1307674368000.0)))))));
-    double sn = r + r * ps;
-    double cs = 1.0 + r2 * (-0.5 + r2 * (1.0 / 24 + r2 * (-1.0 / 720 + r2 * (1.0 / 40320 + r2 * (-1.0 / 3628800 + r2 * (1.0 / 479001600.0 + r2 * (-1.0 / 87178291200.0)))))));
-    switch ((int)(k & 3)) {
-    case 0: *s = sn; *c = cs; break;
-    case 1: *s = cs; *c = -sn; break;
-    case 2: *s = -sn; *c = -cs; break;
-    default: *s = -cs; *c = sn; break;
-    }
-}
-
-BHRT_DM float sinf_(float x)
-{
-    if (!(x == x) || x - x != 0.f) return bitsf(0x7fc00000u);
-    double s, c;
-    sincos_d((double)x, &s, &c);
-    return (float)s;
-}
-BHRT_DM float cosf_(float x)
-{
-    if (!(x == x) || x - x != 0.f) return bitsf(0x7fc00000u);
-    double s, c;
-    sincos_d((double)x, &s, &c);
-    return (float)c;
-}
-BHRT_DM float tanf_(float x)
-{
-    if (!(x == x) || x - x != 0.f) return bitsf(0x7fc00000u);
-    double s, c;
-    sincos_d((double)x, &s, &c);
-    return (float)(s / c);
-}
-
+// ---------------------------------------------------------------------------------------------------------
+// Trigonometric functions: single precision only (full-rate VALU on gfx950), Cody-Waite reduction + the classic
+// Cephes single-precision minimax polynomials, every operation a plain IEEE float op in a fixed order.
+// Accuracy about 1-2 ulp — the same class as libm's own float functions across platforms.
+// ---------------------------------------------------------------------------------------------------------
 BHRT_DM double sqrt_d(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -95,94 +56,112 @@ BHRT_DM double sqrt_d(double x)
     return __builtin_sqrt(x);
 #endif
 }
-
-// atan on [0, +inf) in double
-BHRT_DM double atan_pos_d(double t)
+BHRT_DM float sqrt_f(float x)
 {
-    const double pio2 = 1.57079632679489661923, pio4 = 0.78539816339744830962;
-    double base = 0.0;
-    bool inv = false;
-    if (t > 1.0) { t = 1.0 / t; inv = true; }
-    if (t > 0.41421356237309504880) { t = (t - 1.0) / (t + 1.0); base = pio4; }
-    double z = t * t;
-    // odd series, |t| <= 0.4142 -> z <= 0.1716; 16 terms -> < 1e-13
-    double p = 1.0 / 31;
-    p = 1.0 / 29 - z * p; p = 1.0 / 27 - z * p; p = 1.0 / 25 - z * p; p = 1.0 / 23 - z * p;
-    p = 1.0 / 21 - z * p; p = 1.0 / 19 - z * p; p = 1.0 / 17 - z * p; p = 1.0 / 15 - z * p;
-    p = 1.0 / 13 - z * p; p = 1.0 / 11 - z * p; p = 1.0 / 9 - z * p; p = 1.0 / 7 - z * p;
-    p = 1.0 / 5 - z * p; p = 1.0 / 3 - z * p; p = 1.0 - z * p;
-    double a = base + t * p;
-    return inv ? pio2 - a : a;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fsqrt_rn(x);
+#else
+    return __builtin_sqrtf(x);
+#endif
 }
+BHRT_DM float fabs_f(float x) { return bitsf(fbits(x) & 0x7fffffffu); }
 
-BHRT_DM float atan2f_(float yf, float xf)
+// sin and cos of |x| < 2^20 or so; anything larger or non-finite gives NaN (never produced on this path)
+BHRT_DM void sincos_f(float x, float *s, float *c)
 {
-    const double pi = 3.14159265358979323846;
-    double y = yf, x = xf;
-    if (isnan_d(x) || isnan_d(y)) return bitsf(0x7fc00000u);
-    bool yneg = (fbits(yf) >> 31) != 0, xneg = (fbits(xf) >> 31) != 0;
-    double r;
-    if (y == 0.0) r = xneg ? pi : 0.0;
-    else if (x == 0.0) r = pi / 2;
-    else {
-        double ay = fabs_d(y), ax = fabs_d(x);
-        double a;
-        if (ay == inf_d() && ax == inf_d()) a = pi / 4;
-        else if (ay == inf_d()) a = pi / 2;
-        else if (ax == inf_d()) a = 0.0;
-        else a = atan_pos_d(ay / ax);
-        r = xneg ? pi - a : a;
+    if (!(fabs_f(x) < 1.0e6f)) { *s = *c = bitsf(0x7fc00000u); return; }
+    const float magic = 12582912.0f;                        // 1.5 * 2^23: round-to-nearest-integer by add/subtract
+    const float kf = (x * 0.636619772367581343f + magic) - magic;
+    const int k = (int)kf;
+    // pi/2 in three pieces (2 x the Cephes DP1..DP3): k * P1 is exact for the k that occur here
+    float r = ((x - kf * 1.5703125f) - kf * 4.837512969970703125e-4f) - kf * 7.54978995489188216e-8f;
+    const float z = r * r;
+    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r;
+    ps = ps + r;
+    float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z;
+    pc = pc - 0.5f * z;
+    pc = pc + 1.0f;
+    switch (k & 3) {
+    case 0: *s = ps; *c = pc; break;
+    case 1: *s = pc; *c = -ps; break;
+    case 2: *s = -ps; *c = -pc; break;
+    default: *s = -pc; *c = ps; break;
     }
-    float rf = (float)r;
-    return yneg ? -rf : rf;
+}
+BHRT_DM float sinf_(float x) { float s, c; sincos_f(x, &s, &c); return s; }
+BHRT_DM float cosf_(float x) { float s, c; sincos_f(x, &s, &c); return c; }
+BHRT_DM float tanf_(float x) { float s, c; sincos_f(x, &s, &c); return s / c; }
+
+// asin on [0, 0.5]: x + x * z * P(z), z = x*x (Cephes asinf)
+BHRT_DM float asin_core_f(float x, float z)
+{
+    float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * x;
+    return p + x;
+}
+BHRT_DM float asinf_(float x)
+{
+    const float a = fabs_f(x);
+    if (!(a <= 1.0f)) return bitsf(0x7fc00000u);
+    float r;
+    if (a > 0.5f) {
+        const float z = 0.5f * (1.0f - a);
+        const float t = asin_core_f(sqrt_f(z), z);
+        r = 1.5707963267948966f - (t + t);
+    } else
+        r = asin_core_f(a, a * a);
+    return (fbits(x) >> 31) ? -r : r;
+}
+BHRT_DM float acosf_(float x)
+{
+    if (!(fabs_f(x) <= 1.0f)) return bitsf(0x7fc00000u);
+    if (x > 0.5f) {
+        const float z = 0.5f * (1.0f - x);
+        const float t = asin_core_f(sqrt_f(z), z);
+        return t + t;
+    }
+    if (x < -0.5f) {
+        const float z = 0.5f * (1.0f + x);
+        const float t = asin_core_f(sqrt_f(z), z);
+        return 3.14159265358979323846f - (t + t);
+    }
+    const float a = fabs_f(x);
+    const float t = asin_core_f(a, a * a);
+    return 1.5707963267948966f - ((fbits(x) >> 31) ? -t : t);
+}
+// atan on [0, +inf) (Cephes atanf)
+BHRT_DM float atan_pos_f(float x)
+{
+    float y;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.0f;
+    const float z = x * x;
+    const float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
+    return y + p;
+}
+BHRT_DM float atan2f_(float y, float x)
+{
+    if (x != x || y != y) return bitsf(0x7fc00000u);
+    const bool yneg = (fbits(y) >> 31) != 0, xneg = (fbits(x) >> 31) != 0;
+    const float ay = fabs_f(y), ax = fabs_f(x);
+    const float inf = bitsf(0x7f800000u);
+    float r;
+    if (ay == 0.0f) r = xneg ? 3.14159265358979323846f : 0.0f;
+    else if (ax == 0.0f) r = 1.5707963267948966f;
+    else {
+        float a;
+        if (ay == inf && ax == inf) a = 0.7853981633974483f;
+        else if (ay == inf) a = 1.5707963267948966f;
+        else if (ax == inf) a = 0.0f;
+        else a = atan_pos_f(ay / ax);
+        r = xneg ? 3.14159265358979323846f - a : a;
+    }
+    return yneg ? -r : r;
 }
 
-// asin on [0,1] in double
-BHRT_DM double asin_pos_d(double x)
-{
-    const double pio2 = 1.57079632679489661923;
-    bool big = x > 0.5;
-    double t = x;
-    if (big) t = sqrt_d((1.0 - x) * 0.5);
-    double z = t * t;
-    // asin t = t * sum c_n z^n, c_n = (2n)! / (4^n (n!)^2 (2n+1)) as correctly rounded literals;
-    // z <= 0.25 and 15 terms leave < 1e-11 relative, Horner form, no run-time division
-    double sum = 0.005153309682319905;
-    sum = 0.005740037670841924 + z * sum;
-    sum = 0.006447210311889649 + z * sum;
-    sum = 0.0073125258735988454 + z * sum;
-    sum = 0.008390335809616815 + z * sum;
-    sum = 0.009761609529194078 + z * sum;
-    sum = 0.011551800896139705 + z * sum;
-    sum = 0.01396484375 + z * sum;
-    sum = 0.017352764423076924 + z * sum;
-    sum = 0.022372159090909092 + z * sum;
-    sum = 0.030381944444444444 + z * sum;
-    sum = 0.044642857142857144 + z * sum;
-    sum = 0.075 + z * sum;
-    sum = 0.16666666666666666 + z * sum;
-    sum = 1.0 + z * sum;
-    double a = t * sum;
-    return big ? pio2 - 2.0 * a : a;
-}
-BHRT_DM float asinf_(float xf)
-{
-    double x = xf;
-    if (isnan_d(x) || fabs_d(x) > 1.0) return bitsf(0x7fc00000u);
-    double a = asin_pos_d(fabs_d(x));
-    return (float)(x < 0 ? -a : a);
-}
-BHRT_DM float acosf_(float xf)
-{
-    const double pi = 3.14159265358979323846, pio2 = 1.57079632679489661923;
-    double x = xf;
-    if (isnan_d(x) || fabs_d(x) > 1.0) return bitsf(0x7fc00000u);
-    double r;
-    if (x > 0.5) r = 2.0 * asin_pos_d(sqrt_d((1.0 - x) * 0.5));
-    else if (x < -0.5) r = pi - 2.0 * asin_pos_d(sqrt_d((1.0 + x) * 0.5));
-    else r = pio2 - (x < 0 ? -asin_pos_d(-x) : asin_pos_d(x));
-    return (float)r;
-}
+// (double)r / RAND_MAX of the reference's Rnd01 (MtlBlinn.cpp:43) as one multiplication: the device-math form of
+// the conversion (the sequential/libm oracle mode keeps the division, which is what the compiled reference does)
+BHRT_DM float rand_to_unit(int r) { return (float)((double)r * 4.656612875245796924105750827168e-10); }
 
 // natural log of a positive finite double
 BHRT_DM double log_pos_d(double x)
@@ -198,7 +177,11 @@ BHRT_DM double log_pos_d(double x)
     e -= 1023;
     double m = bitsd((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL); // [1,2)
     if (m > 1.41421356237309504880) { m = m * 0.5; e += 1; }
-    double s = (m - 1.0) / (m + 1.0); // |s| <= 0.1716
+    // s = (m-1)/(m+1), |s| <= 0.1716: reciprocal seeded by ONE float division and refined in double (error ~2^-46)
+    const double den = m + 1.0;
+    const double r0 = (double)(1.0f / (float)den);
+    const double r1 = r0 * (2.0 - den * r0);
+    double s = (m - 1.0) * r1;
     double z = s * s;
     double p = 1.0 / 23;
     p = 1.0 / 21 + z * p; p = 1.0 / 19 + z * p; p = 1.0 / 17 + z * p; p = 1.0 / 15 + z * p;

@@ -182,9 +182,9 @@ struct DRng {
     __device__ int rand() { return bhrt_rand31(key, ctr++); }
     __device__ float rnd01() // MtlBlinn.cpp:42-49
     {
-        float r = (float)((double)rand() / (BHRT_RAND_MAX));
+        float r = dm::rand_to_unit(rand());
         int guard = 0;
-        while ((r == 0.0f || r == 1.0f) && guard++ < BHRT_MAXLOOP) r = (float)((double)rand() / (BHRT_RAND_MAX));
+        while ((r == 0.0f || r == 1.0f) && guard++ < BHRT_MAXLOOP) r = dm::rand_to_unit(rand());
         return r;
     }
 };

@@ -37,7 +37,7 @@ enum : uint32_t { FH_ROOT = 0, FH_GI = 1, FH_REFR_FRONT = 2, FH_REFR_OUT = 3 };
 // direct-light term state of a frame
 enum : uint32_t { DM_NONE = 0, DM_AMBIENT = 1, DM_DIRECT = 2, DM_POINT = 3, DM_POINT_ZERO = 4 };
 // frame flags
-enum : uint32_t { FF_CONST = 1u /* value in refr */, FF_HAS_REFR_COLOR = 2u };
+enum : uint32_t { FF_CONST = 1u /* value in refr */, FF_HAS_REFR = 2u /* a refraction ray was emitted: refr + refr_color valid */, FF_HAS_GI = 4u };
 
 // Closest-hit ray queue (SoA, one array per field -> coalesced)
 struct RayQueue {

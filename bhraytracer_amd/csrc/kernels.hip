@@ -194,8 +194,8 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
     const int mi = S.nodes[node].material;
     uint32_t flags = 0, dmode = DM_NONE, light_idx = 0;
     V3 zero = v3(0, 0, 0);
-    st3(F.refr, f, zero); st3(F.gi, f, zero); st3(F.brdf, f, zero); st3(F.gi_mult, f, zero); st3(F.refr_color, f, zero); st3(F.caustic, f, zero);
-    F.rr[f] = 1.f; F.vis[f] = 1.f;
+    // no zero-fill of the term arrays: the flags in `info` say which terms exist (k_combine reads only those)
+    if (R.photon) st3(F.caustic, f, zero);
     if (mi < 0 || S.materials[mi].kind != BHRT_MTL_BLINN) {
         // node without material: black (the reference dereferences null); empty MultiMtl: white (materials.h:71)
         flags = FF_CONST;
@@ -251,7 +251,7 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
         out.rmeta = make_meta(RK_REFR_IN, BHRT_HIT_FRONT_AND_BACK, bounce);
         out.rctr = g.ctr;
         st3(F.refr_color, f, refraction);
-        flags |= FF_HAS_REFR_COLOR;
+        flags |= FF_HAS_REFR;
     }
     // ---- global illumination, PathTracing_GlobalIllumination (MtlBlinn.cpp:383-433)
     const bool textured = m.diffuse.map >= 0 || newSpecular.map >= 0;
@@ -263,6 +263,7 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
         out.gd = gi_direction(g, useSpecular, vN, vV, tc_max(m.diffuse.color), tc_max(newSpecular.color), m.glossiness);
         out.go = a.p + vN * BHRT_BIAS;
         out.has_gi = true;
+        flags |= FF_HAS_GI;
         const bhrt_texcolor &tcs = useSpecular ? newSpecular : m.diffuse;
         st3(F.gi_mult, f, textured ? tc_sample_d(S, tcs, a.uvw, a.du, a.dv) : ld3(tcs.color));
     }
@@ -392,7 +393,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene S, RenderParams 
         F.info2[f] = (uint32_t)(gi + 64) | ((uint32_t)(bounce & 0xff) << 8);
         F.skey[f] = skey;
         F.code[f] = code;
-        st3(F.mult, f, mult);
+        if (how == FH_GI || how == FH_REFR_OUT) st3(F.mult, f, mult);
         const int mi = S.nodes[hit.node].material;
         const bool need_uv = mi >= 0 && (S.materials[mi].diffuse.map >= 0 || S.materials[mi].specular.map >= 0);
         Attr a;
@@ -495,7 +496,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene S, RenderParams 
 
 // ------------------------------------------------------------------------------------------------
 // Fold frames [f0, f1) (all created in one wave step) into their parents / the sample buffer.
-__global__ void __launch_bounds__(kBlock) k_combine(DevScene S, Frames F, uint32_t f0, uint32_t f1, float *samples)
+__global__ void __launch_bounds__(kBlock) k_combine(DevScene S, Frames F, uint32_t f0, uint32_t f1, float *samples, int photon)
 {
     const uint32_t f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= f1) return;
@@ -506,10 +507,10 @@ __global__ void __launch_bounds__(kBlock) k_combine(DevScene S, Frames F, uint32
     else {
         // Shade(), MtlBlinn.cpp:117-137
         out = v3(0, 0, 0);
-        out = out + ld3i(F.refr, f);
+        if (flags & FF_HAS_REFR) out = out + ld3i(F.refr, f); // else PathTracing_Refraction returned black
         bool done = out.x >= 1 && out.y >= 1 && out.z >= 1;
         if (!done) {
-            out = out + ld3i(F.gi, f);
+            if (flags & FF_HAS_GI) out = out + ld3i(F.gi, f);  // else gi < 0: black (MtlBlinn.cpp:386)
             done = out.x >= 1 && out.y >= 1 && out.z >= 1;
         }
         if (!done) {
@@ -525,7 +526,7 @@ __global__ void __launch_bounds__(kBlock) k_combine(DevScene S, Frames F, uint32
                 else irrad = v3(1, 1, 1) * BHRT_BIGFLOAT;                           // PointLight.cpp:12
                 dc = dc + irrad * ld3i(F.brdf, f);
             }
-            dc = dc + ld3i(F.caustic, f);
+            if (photon) dc = dc + ld3i(F.caustic, f);
             dc = clamp_white(dc);
             if (isnan_f(dc.x)) dc = v3(0, 0, 0);
             out = out + dc;
@@ -924,7 +925,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             Timer t(D, &st->seconds_other);
             for (size_t k = frame_marks.size(); k-- > 1;) {
                 const uint32_t f0 = frame_marks[k - 1], f1 = frame_marks[k];
-                if (f1 > f0) hipLaunchKernelGGL(k_combine, dim3((f1 - f0 + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, F, f0, f1, D->d_samples);
+                if (f1 > f0) hipLaunchKernelGGL(k_combine, dim3((f1 - f0 + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, F, f0, f1, D->d_samples, o.photon_map);
             }
             hipLaunchKernelGGL(k_resolve, dim3((npx + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, P, D->d_samples, d_radiance, d_rgb8);
             if (d_region_samples)

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -208,11 +209,13 @@ struct Rng {
         ctr = 0;
     }
     int Rand() { return bhrt_rand31(key, ctr++); }
+    bool device_math = false; // device-math mode converts with one multiplication (bhrt_detmath.h::rand_to_unit)
+    float ToUnit(int r) const { return device_math ? bhrt::dm::rand_to_unit(r) : (float)((double)r / (BHRT_RAND_MAX)); }
     float Rnd01() // MtlBlinn.cpp:42-49
     {
-        float rnd = (float)((double)Rand() / (BHRT_RAND_MAX));
+        float rnd = ToUnit(Rand());
         int guard = 0;
-        while ((rnd == 0.0f || rnd == 1.0f) && guard++ < O_MAXLOOP) rnd = (float)((double)Rand() / (BHRT_RAND_MAX));
+        while ((rnd == 0.0f || rnd == 1.0f) && guard++ < O_MAXLOOP) rnd = ToUnit(Rand());
         return rnd;
     }
 };
@@ -1027,6 +1030,7 @@ int RenderT(const Scene &S, const oracle_opts &o, float *samples, float *radianc
         Tracer<M> T(S, &cnt);
         Rng rng;
         rng.keyed = o.rng_mode == ORACLE_RNG_KEYED;
+        rng.device_math = std::is_same<M, MathDevice>::value;
         Shader<M> sh(S, T, X, rng, &cnt, o.photon_gather != 0);
         const int j = y0 + jj;
         for (int i = x0; i < x1; i++) {
@@ -1628,6 +1632,7 @@ template <class M> struct PhotonTracer {
         for (auto *l : pl) sum += key(l);
         uint64_t emitted = 0;
         rng.keyed = false;
+        rng.device_math = std::is_same<M, MathDevice>::value;
         rng.key = bhrt_photon_key_sequential(seed);
         rng.ctr = 0;
         while (pm.numStored < maxPhotons) {
