@@ -59,7 +59,7 @@ EXPORTS = [
     "bhrt_scene_warning", "bhrt_scene_flat", "bhrt_scene_upload", "bhrt_device_count",
     "bhrt_trace_closest_host", "bhrt_trace_closest_dev", "bhrt_trace_shadow_host", "bhrt_trace_shadow_dev",
     "bhrt_render", "bhrt_render_dev", "bhrt_render_samples", "bhrt_photon_build", "bhrt_photon_gather_host",
-    "bhrt_photon_get", "bhrt_photon_export", "bhrt_save_png",
+    "bhrt_photon_get", "bhrt_photon_export", "bhrt_save_png", "bhrt_math_eval_dev",
 ]
 
 
@@ -222,6 +222,14 @@ class Scene:
         st = Stats()
         _check(lib().bhrt_render_samples(self._h, C.byref(opts), x0, y0, x1, y1, _ptr(out), C.byref(st)))
         return out, st
+
+
+def math_eval_dev(fn: int, a, b=None):
+    a = np.ascontiguousarray(a, np.float32)
+    bb = np.ascontiguousarray(b, np.float32) if b is not None else None
+    out = np.empty_like(a)
+    _check(lib().bhrt_math_eval_dev(int(fn), _ptr(a), _ptr(bb) if bb is not None else None, C.c_size_t(a.size), _ptr(out)))
+    return out
 
 
 def save_png(path: str, rgb8: np.ndarray):

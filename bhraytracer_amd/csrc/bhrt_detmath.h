@@ -12,6 +12,7 @@
 // double-precision log/exp), i.e. the accuracy class of libm's own float functions; the oracle's libm mode (pinned against the compiled reference) and its
 // device-math mode are compared statistically in tests/.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -48,22 +49,10 @@ BHRT_DM double pow2i(int k) { return bitsd((uint64_t)(k + 1023) << 52); }
 // Cephes single-precision minimax polynomials, every operation a plain IEEE float op in a fixed order.
 // Accuracy about 1-2 ulp — the same class as libm's own float functions across platforms.
 // ---------------------------------------------------------------------------------------------------------
-BHRT_DM double sqrt_d(double x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __dsqrt_rn(x);
-#else
-    return __builtin_sqrt(x);
-#endif
-}
-BHRT_DM float sqrt_f(float x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fsqrt_rn(x);
-#else
-    return __builtin_sqrtf(x);
-#endif
-}
+// correctly rounded square roots: sqrt()/sqrtf() are IEEE on both sides (hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt); HIP's __fsqrt_rn is NOT (it lowers to the native approximation)
+BHRT_DM double sqrt_d(double x) { return sqrt(x); }
+BHRT_DM float sqrt_f(float x) { return sqrtf(x); }
 BHRT_DM float fabs_f(float x) { return bitsf(fbits(x) & 0x7fffffffu); }
 
 // sin and cos of |x| < 2^20 or so; anything larger or non-finite gives NaN (never produced on this path)

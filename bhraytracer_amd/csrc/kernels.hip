@@ -569,6 +569,28 @@ __global__ void __launch_bounds__(kBlock) k_resolve(PassInfo P, const float *sam
     }
 }
 
+// test hook: the deterministic math of bhrt_detmath.h evaluated on the device (tests compare its bits with the host's)
+__global__ void k_math_eval(int fn, const float *a, const float *b, uint32_t n, float *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b ? b[i] : 0.f;
+    float r = 0;
+    switch (fn) {
+    case 0: r = dm::sinf_(x); break;
+    case 1: r = dm::cosf_(x); break;
+    case 2: r = dm::tanf_(x); break;
+    case 3: r = dm::acosf_(x); break;
+    case 4: r = dm::asinf_(x); break;
+    case 5: r = dm::atan2f_(x, y); break;
+    case 6: r = dm::powf_(x, y); break;
+    case 7: r = dm::rand_to_unit((int)dm::fbits(x)); break;
+    case 8: r = x / y; break;
+    case 9: r = sqrtf(x); break;
+    }
+    out[i] = r;
+}
+
 __global__ void k_copy_samples(PassInfo P, const float *samples, int x0, int y0, int x1, int y1, float *out)
 {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1151,6 +1173,23 @@ int bhrt_render_samples(bhrt_scene *scene, const bhrt_opts *opts, int x0, int y0
 }
 
 // ---- caustic photon map --------------------------------------------------------------------------
+int bhrt_math_eval_dev(int fn, const float *a, const float *b, size_t n, float *out)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { SetError("no HIP device available"); return BHRT_ERR_NO_DEVICE; }
+    if (!a || !out || fn < 0 || fn > 9) { SetError("bad argument"); return BHRT_ERR_ARG; }
+    if (n == 0) return BHRT_OK;
+    float *d = nullptr;
+    HIP_CHECK(hipMalloc(&d, n * 3 * sizeof(float)));
+    HIP_CHECK(hipMemcpy(d, a, n * sizeof(float), hipMemcpyHostToDevice));
+    if (b) HIP_CHECK(hipMemcpy(d + n, b, n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_math_eval, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, fn, d, b ? d + n : nullptr, (uint32_t)n, d + 2 * n);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return BHRT_OK;
+}
+
 int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, uint32_t *n_stored)
 {
     int rc = EnsureUploaded(scene);

@@ -129,6 +129,10 @@ int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *n, s
 int bhrt_photon_get(const bhrt_scene *scene, void *photons_out /* 24 B records, balanced order */, uint32_t capacity, uint32_t *n);
 int bhrt_photon_export(const bhrt_scene *scene, const char *dat_path); /* 24-byte records, Main.cpp:383-385 */
 
+/* ---- test hook: csrc/bhrt_detmath.h evaluated on the device, to prove host and device produce the same bits.
+ * fn: 0 sin 1 cos 2 tan 3 acos 4 asin 5 atan2(a,b) 6 pow(a,b) 7 rand_to_unit(bits of a) 8 a/b 9 sqrt(a); host pointers */
+int bhrt_math_eval_dev(int fn, const float *a, const float *b, size_t n, float *out);
+
 /* ---- image output (RenderImage::SaveImage, Scenes/scene.h:628-644) ------------------------------- */
 int bhrt_save_png(const char *path, const uint8_t *rgb8, int width, int height);
 

@@ -1154,6 +1154,9 @@ int oracle_math_eval(int fn, int math_mode, const float *a, const float *b, size
             case 4: out[i] = MathDevice::Asin(x); break;
             case 5: out[i] = MathDevice::Atan2(x, y); break;
             case 6: out[i] = MathDevice::Pow(x, y); break;
+            case 7: { uint32_t u; memcpy(&u, &x, 4); out[i] = bhrt::dm::rand_to_unit((int)u); } break;
+            case 8: out[i] = x / y; break;
+            case 9: out[i] = sqrtf(x); break;
             default: return 1;
             }
         } else {

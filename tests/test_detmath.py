@@ -59,3 +59,32 @@ def test_special_values(O):
         dev, ref = O.math_eval(fn, O.MATH_DEVICE, x), O.math_eval(fn, O.MATH_LIBM, x)
         assert np.array_equal(np.isnan(dev), np.isnan(ref))
         assert np.allclose(dev[:3], ref[:3], atol=2e-7)
+
+
+@pytest.mark.gpu
+def test_device_bits_equal_host_bits(B, O):
+    """The whole point of bhrt_detmath.h: gfx950 and x86-64 produce IDENTICAL bits (plus IEEE / and sqrt)."""
+    if B.device_count() < 1:
+        pytest.fail("no HIP device")
+    rng = np.random.RandomState(11)
+    n = 1 << 20
+    wide = (rng.standard_normal(n) * np.exp(rng.uniform(-20, 20, n))).astype(np.float32)
+    cases = [
+        (0, rng.uniform(-50, 50, n), None), (1, rng.uniform(-50, 50, n), None), (2, rng.uniform(-1.6, 1.6, n), None),
+        (0, rng.uniform(0, 6.2832, n), None), (1, rng.uniform(0, 6.2832, n), None), (2, rng.uniform(0, 1.5708, n), None),
+        (3, rng.uniform(-1.001, 1.001, n), None), (4, rng.uniform(-1.001, 1.001, n), None),
+        (3, 1 - np.exp(rng.uniform(-30, 0, n)), None),
+        (5, rng.standard_normal(n), rng.standard_normal(n)), (5, wide, wide[::-1].copy()),
+        (6, rng.uniform(0, 1, n), rng.choice([1 / 21.0, 1 / 11.0, 1 / 20001.0, 1 / 200001.0, 20, 10, 20000, 200000, 1 / 2.2, 1.5, 5, 2], n)),
+        (6, np.full(n, 2.7182818), -rng.uniform(0, 100, n)), (6, rng.uniform(-2, 2, n), rng.randint(-4, 40, n).astype(np.float32)),
+        (6, np.abs(wide), rng.uniform(-3, 3, n)),
+        (7, rng.randint(0, 2**31 - 1, n).astype(np.uint32).view(np.float32), None),
+        (8, wide, wide[::-1].copy()), (8, rng.uniform(-30, 30, n), rng.uniform(-1, 1, n)), (9, np.abs(wide), None),
+    ]
+    for fn, a, b in cases:
+        a = np.asarray(a, np.float32)
+        b = None if b is None else np.asarray(b, np.float32)
+        dev = B.math_eval_dev(fn, a, b)
+        host = O.math_eval(fn, O.MATH_DEVICE, a, b)
+        same = (dev.view(np.uint32) == host.view(np.uint32)) | (np.isnan(dev) & np.isnan(host))
+        assert same.all(), f"fn {fn}: {np.count_nonzero(~same)} of {n} differ, e.g. a={a[~same][:3]} b={None if b is None else b[~same][:3]} dev={dev[~same][:3]} host={host[~same][:3]}"
