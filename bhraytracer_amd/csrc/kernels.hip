@@ -110,6 +110,9 @@ __device__ inline void block_alloc3(BlockAllocLds &L, uint32_t *c0, uint32_t n0a
     __syncthreads(); // L may be reused by the next call
 }
 
+// per-sample radiance buffer is sample-major: [sample][pixel of the pass] -> k_resolve reads coalesced
+__device__ inline uint32_t sample_addr(const PassInfo &P, uint32_t slot) { return (slot % (uint32_t)P.spp) * P.n_pixels + slot / (uint32_t)P.spp; }
+
 __device__ inline void put_ray(const RayQueue &q, uint32_t i, V3 o, V3 d, uint32_t frame, uint32_t meta, uint32_t ctr)
 {
     q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z; q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
@@ -405,7 +408,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene S, RenderParams 
             // background.Sample((i/W, j/H, 0)), Main.cpp:166-167
             int pi, pj;
             pixel_of(P, P.q0 + owner / (uint32_t)P.spp, pi, pj);
-            st3(samples, owner, tc_sample(S, S.background, v3((float)pi / S.cam.width, (float)pj / S.cam.height, 0.0f)));
+            st3(samples, sample_addr(P, owner), tc_sample(S, S.background, v3((float)pi / S.cam.width, (float)pj / S.cam.height, 0.0f)));
         } else if (kind == RK_GI) {
             V3 mult = ld3i(F.gi_mult, owner);
             V3 outc = v3(0, 0, 0);
@@ -496,7 +499,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene S, RenderParams 
 
 // ------------------------------------------------------------------------------------------------
 // Fold frames [f0, f1) (all created in one wave step) into their parents / the sample buffer.
-__global__ void __launch_bounds__(kBlock) k_combine(DevScene S, Frames F, uint32_t f0, uint32_t f1, float *samples, int photon)
+__global__ void __launch_bounds__(kBlock) k_combine(DevScene S, PassInfo P, Frames F, uint32_t f0, uint32_t f1, float *samples, int photon)
 {
     const uint32_t f = f0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= f1) return;
@@ -535,7 +538,7 @@ __global__ void __launch_bounds__(kBlock) k_combine(DevScene S, Frames F, uint32
         }
     }
     const uint32_t parent = F.parent[f];
-    if (how == FH_ROOT) st3(samples, parent, out);
+    if (how == FH_ROOT) st3(samples, sample_addr(P, parent), out);
     else if (how == FH_GI) { // MtlBlinn.cpp:406,427-432
         V3 oc = v3(0, 0, 0) + out * ld3i(F.mult, f);
         if (isnan_f(oc.x)) oc = v3(1.0f, 0.0f, 1.0f);
@@ -553,7 +556,7 @@ __global__ void __launch_bounds__(kBlock) k_resolve(PassInfo P, const float *sam
     int i, j;
     if (!pixel_of(P, P.q0 + q, i, j)) return;
     V3 sum = v3(0, 0, 0);
-    for (int s = 0; s < P.spp; s++) sum = sum + ld3i(samples, q * (uint32_t)P.spp + (uint32_t)s);
+    for (int s = 0; s < P.spp; s++) sum = sum + ld3i(samples, (uint32_t)s * P.n_pixels + q);
     V3 out = sum / (float)P.spp;
     const size_t pix = (size_t)j * P.W + i;
     if (radiance) st3(radiance, (uint32_t)pix, out);
@@ -600,7 +603,7 @@ __global__ void k_copy_samples(PassInfo P, const float *samples, int x0, int y0,
     if (i < x0 || i >= x1 || j < y0 || j >= y1) return;
     const size_t pix = (size_t)(j - y0) * (x1 - x0) + (i - x0);
     for (int s = 0; s < P.spp; s++)
-        for (int c = 0; c < 3; c++) out[(pix * P.spp + s) * 3 + c] = samples[((size_t)q * P.spp + s) * 3 + c];
+        for (int c = 0; c < 3; c++) out[(pix * P.spp + s) * 3 + c] = samples[((size_t)s * P.n_pixels + q) * 3 + c];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -686,6 +689,10 @@ struct DeviceState {
     Counters *h_cnt = nullptr; // pinned
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    struct PendingTimer { int e0, e1; double *acc; };
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<PendingTimer> ev_pending;
+    int ev_used = 0;
     // caustic photon map (balanced, heap order, slot 0 unused) + gather scratch
     DPhoton *d_photons = nullptr;
     uint32_t n_photons = 0;
@@ -712,6 +719,7 @@ void DestroyDeviceState(DeviceState *d)
     fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr_d2); fr(d->d_scr_idx);
     if (d->h_cnt) (void)hipHostFree(d->h_cnt);
     for (int k = 0; k < 2; k++) if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
+    for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -796,19 +804,35 @@ static uint64_t CountValidPixels(const PassInfo &P, uint32_t n)
     return valid;
 }
 
+// Kernel timing with HIP events on the library's stream, without a host round trip per kernel: start/stop events
+// come from a pool and are only read back (FlushTimers) after a stream synchronisation the pipeline needs anyway.
 struct Timer {
     DeviceState *D;
     double *acc;
-    Timer(DeviceState *d, double *a) : D(d), acc(a) { (void)hipEventRecord(D->ev[0], D->stream); }
+    int e0;
+    static hipEvent_t Get(DeviceState *d, int &idx)
+    {
+        if (d->ev_used == (int)d->ev_pool.size()) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); d->ev_pool.push_back(e); }
+        idx = d->ev_used++;
+        return d->ev_pool[idx];
+    }
+    Timer(DeviceState *d, double *a) : D(d), acc(a) { (void)hipEventRecord(Get(D, e0), D->stream); }
     void Stop()
     {
-        (void)hipEventRecord(D->ev[1], D->stream);
-        (void)hipEventSynchronize(D->ev[1]);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, D->ev[0], D->ev[1]);
-        *acc += ms * 1e-3;
+        int e1;
+        (void)hipEventRecord(Get(D, e1), D->stream);
+        D->ev_pending.push_back({e0, e1, acc});
     }
 };
+static void FlushTimers(DeviceState *D) // call after the stream has been synchronised
+{
+    for (auto &p : D->ev_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, D->ev_pool[p.e0], D->ev_pool[p.e1]) == hipSuccess) *p.acc += ms * 1e-3;
+    }
+    D->ev_pending.clear();
+    D->ev_used = 0;
+}
 
 static int EnsurePhotonScratch(DeviceState *D, uint32_t lanes)
 {
@@ -906,6 +930,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             }
             HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, D->stream));
             HIP_CHECK(hipStreamSynchronize(D->stream));
+            FlushTimers(D);
             if (D->h_cnt->overflow) { overflow = true; break; }
             if (first_step) { // camera step: dead rays of edge tiles are not rays
                 const uint64_t valid_px = CountValidPixels(P, npx);
@@ -947,7 +972,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             Timer t(D, &st->seconds_other);
             for (size_t k = frame_marks.size(); k-- > 1;) {
                 const uint32_t f0 = frame_marks[k - 1], f1 = frame_marks[k];
-                if (f1 > f0) hipLaunchKernelGGL(k_combine, dim3((f1 - f0 + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, F, f0, f1, D->d_samples, o.photon_map);
+                if (f1 > f0) hipLaunchKernelGGL(k_combine, dim3((f1 - f0 + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, P, F, f0, f1, D->d_samples, o.photon_map);
             }
             hipLaunchKernelGGL(k_resolve, dim3((npx + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, P, D->d_samples, d_radiance, d_rgb8);
             if (d_region_samples)
@@ -959,6 +984,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         q += npx;
     }
     HIP_CHECK(hipStreamSynchronize(D->stream));
+    FlushTimers(D);
     st->seconds_total += std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
     return BHRT_OK;
 }
