@@ -151,16 +151,14 @@ __device__ inline bool tri_hit(const bhrt_tri &tr, V3 o, V3 d, float dlen, int s
 
 struct MeshRef {
     const bhrt_bvh_node *bvh;
-    const uint32_t *elems;
-    const bhrt_tri *tris;
+    const bhrt_tri *ltris; // leaf order: ltris[off + i] is the i-th triangle of the leaf with element offset `off`
 };
 __device__ inline MeshRef mesh_ref(const DevScene &S, int mi)
 {
     const bhrt_mesh &m = S.meshes[mi];
     MeshRef r;
     r.bvh = (const bhrt_bvh_node *)(S.blob + m.off_bvh);
-    r.elems = (const uint32_t *)(S.blob + m.off_elems);
-    r.tris = (const bhrt_tri *)(S.blob + m.off_tris);
+    r.ltris = (const bhrt_tri *)(S.blob + m.off_leaf_tris);
     return r;
 }
 
@@ -214,10 +212,10 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
             const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
             r = false;
             for (uint32_t i = 0; i < count; i++) {
-                const uint32_t face = M.elems[off + i];
+                const bhrt_tri &tr = M.ltris[off + i];
                 float t;
                 int fr;
-                if (tri_hit(M.tris[face], o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)face; hfront = fr; r = true; }
+                if (tri_hit(tr, o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)tr.face; hfront = fr; r = true; }
             }
             any |= r;
             desc = false;
@@ -264,7 +262,7 @@ __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
     int depth = 0;
     bool desc = true, found = false;
     float t_min = BHRT_BIGFLOAT;
-    while (true) {
+    while (true) { // single-loop state machine (measured faster than the phased form for any-hit rays)
         if (desc) {
             const uint32_t data = M.bvh[cur].data;
             if (data & 0x80000000u) {
@@ -273,7 +271,7 @@ __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
                 for (uint32_t i = 0; i < count; i++) {
                     float t;
                     int fr;
-                    if (tri_hit(M.tris[M.elems[off + i]], o, d, dlen, BHRT_HIT_FRONT, ht, t, fr)) { ht = t; found = true; t_min = t; }
+                    if (tri_hit(M.ltris[off + i], o, d, dlen, BHRT_HIT_FRONT, ht, t, fr)) { ht = t; found = true; t_min = t; }
                 }
                 if (found) break;
                 desc = false;

@@ -1015,8 +1015,12 @@ int LoadSceneXml(const char *path, FlatScene &out, std::string &err)
             tris[f].vN[0] = vN.x; tris[f].vN[1] = vN.y; tris[f].vN[2] = vN.z;
             tris[f].vN_len = length(vN);
             tris[f].vN_dot_v0 = dot(vN, a);
+            tris[f].face = f;
         }
         o.off_tris = W.Append(tris.data(), tris.size() * sizeof(bhrt_tri));
+        std::vector<bhrt_tri> leaf_tris(o.nf);
+        for (uint32_t k = 0; k < o.nf; k++) leaf_tris[k] = tris[m.elems[k]];
+        o.off_leaf_tris = W.Append(leaf_tris.data(), leaf_tris.size() * sizeof(bhrt_tri));
         memcpy(o.bound_min, m.bound_min, 12);
         memcpy(o.bound_max, m.bound_max, 12);
     }

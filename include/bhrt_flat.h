@@ -20,7 +20,7 @@
 #include <stdint.h>
 
 #define BHRT_FLAT_MAGIC 0x54524842u /* "BHRT" */
-#define BHRT_FLAT_VERSION 4u
+#define BHRT_FLAT_VERSION 5u
 #define BHRT_MAX_NODE_DEPTH 8 /* scene-graph depth below the root the kernels support */
 #define BHRT_BIGFLOAT 1.0e30f  /* Scenes/scene.h:38 */
 
@@ -67,7 +67,8 @@ typedef struct bhrt_tri {
     float vN[3];
     float vN_len;
     float vN_dot_v0;
-    float pad[2];
+    uint32_t face; /* triangle id (index into f[]) — lets the leaf-ordered copy skip the element-id indirection */
+    float pad;
 } bhrt_tri;
 
 typedef struct bhrt_mesh {
@@ -79,7 +80,8 @@ typedef struct bhrt_mesh {
     uint64_t off_f, off_fn, off_ft;    /* uint32[3] each (fn/ft always present: nvn/nvt > 0 is enforced) */
     uint64_t off_bvh;                  /* bhrt_bvh_node[n_bvh_nodes] */
     uint64_t off_elems;                /* uint32[nf] */
-    uint64_t off_tris;                 /* bhrt_tri[nf] */
+    uint64_t off_tris;                 /* bhrt_tri[nf], indexed by triangle id */
+    uint64_t off_leaf_tris;            /* bhrt_tri[nf] in BVH leaf order: entry k = triangle elems[k] (one load instead of two dependent ones) */
     float bound_min[3], bound_max[3];  /* cyTriMesh::ComputeBoundingBox */
 } bhrt_mesh;
 
