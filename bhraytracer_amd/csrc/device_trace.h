@@ -150,17 +150,44 @@ __device__ inline bool tri_hit(const bhrt_tri &tr, V3 o, V3 d, float dlen, int s
 }
 
 struct MeshRef {
-    const bhrt_bvh_node *bvh;
-    const bhrt_tri *ltris; // leaf order: ltris[off + i] is the i-th triangle of the leaf with element offset `off`
+    const bhrt_bvh_node *bvh;  // breadth-first numbered tree (bhrt_mesh::off_dbvh)
+    const bhrt_tri *ltris;     // leaf order: ltris[off + i] is the i-th triangle of the leaf with element offset `off`
+    const bhrt_bvh_node *lds;  // the first `n_lds` nodes (= the top levels) staged in LDS by the workgroup, or nullptr
+    uint32_t n_lds;
 };
 __device__ inline MeshRef mesh_ref(const DevScene &S, int mi)
 {
     const bhrt_mesh &m = S.meshes[mi];
     MeshRef r;
-    r.bvh = (const bhrt_bvh_node *)(S.blob + m.off_bvh);
+    r.bvh = (const bhrt_bvh_node *)(S.blob + m.off_dbvh);
     r.ltris = (const bhrt_tri *)(S.blob + m.off_leaf_tris);
+    r.lds = nullptr;
+    r.n_lds = 0;
     return r;
 }
+// one BVH node (32 B) from the LDS nodelet when it is one of the staged top levels, else from global memory
+struct NodeRec {
+    float b[6];
+    uint32_t data, parent;
+};
+__device__ inline NodeRec node_at(const MeshRef &M, uint32_t i)
+{
+    NodeRec n;
+    if (i < M.n_lds) {
+        const float4 *p = (const float4 *)(M.lds + i);
+        const float4 a = p[0], c = p[1];
+        n.b[0] = a.x; n.b[1] = a.y; n.b[2] = a.z; n.b[3] = a.w; n.b[4] = c.x; n.b[5] = c.y;
+        n.data = __float_as_uint(c.z); n.parent = __float_as_uint(c.w);
+    } else {
+        const float4 *p = (const float4 *)(M.bvh + i);
+        const float4 a = p[0], c = p[1];
+        n.b[0] = a.x; n.b[1] = a.y; n.b[2] = a.z; n.b[3] = a.w; n.b[4] = c.x; n.b[5] = c.y;
+        n.data = __float_as_uint(c.z); n.parent = __float_as_uint(c.w);
+    }
+    return n;
+}
+__device__ inline uint32_t node_parent(const MeshRef &M, uint32_t i) { return i < M.n_lds ? M.lds[i].parent : M.bvh[i].parent; }
+__device__ inline uint32_t node_data(const MeshRef &M, uint32_t i) { return i < M.n_lds ? M.lds[i].data : M.bvh[i].data; }
 
 // TriObj::IntersectRay + TraceBVHNode (TriObj.cpp:17-39,192-270) as a stackless state machine.
 //   descending into a node: leaf -> test its <=4 triangles in order; inner -> test both child boxes with
@@ -177,13 +204,14 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
 {
     float tm;
     const RayRcp rr = ray_rcp(d);
-    if (!box_hit_rcp(M.bvh[1].b, o, d, rr, ht, tm)) return false;
+    const NodeRec root = node_at(M, 1);
+    if (!box_hit_rcp(root.b, o, d, rr, ht, tm)) return false;
     const float dlen = length(d);
     uint32_t cur = 1;
     int depth = 0;
     uint64_t inFar = 0, nearHit = 0;
     bool desc = true, r = false, any = false;
-    uint32_t data = M.bvh[1].data;
+    uint32_t data = root.data;
     // "while-while" form of the state machine: the lanes of a wave run the three phases together (descend through
     // inner nodes / test a leaf / climb), so a wave executes max-per-phase work instead of the union of all
     // three bodies on every step.
@@ -192,7 +220,7 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
         while (desc && !(data & 0x80000000u)) {
             const uint32_t c1 = data & 0x7fffffffu;
             float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
-            const bhrt_bvh_node &n1 = M.bvh[c1], &n2 = M.bvh[c1 + 1];
+            const NodeRec n1 = node_at(M, c1), n2 = node_at(M, c1 + 1);
             const uint32_t d1 = n1.data, d2 = n2.data;
             bool b1 = box_hit_rcp(n1.b, o, d, rr, ht, tmin1);
             bool b2 = box_hit_rcp(n2.b, o, d, rr, ht, tmin2);
@@ -228,19 +256,19 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
                 if (r) {
                     nearHit |= bit;
                     float tmf;
-                    const bhrt_bvh_node &ns = M.bvh[sib];
+                    const NodeRec ns = node_at(M, sib);
                     const uint32_t ds = ns.data;
                     if (box_hit_rcp(ns.b, o, d, rr, ht, tmf)) { inFar |= bit; cur = sib; data = ds; desc = true; }
-                    else { cur = M.bvh[cur].parent; depth--; /* r stays true */ }
+                    else { cur = node_parent(M, cur); depth--; /* r stays true */ }
                 } else {
                     inFar |= bit;
                     cur = sib;
-                    data = M.bvh[sib].data;
+                    data = node_data(M, sib);
                     desc = true;
                 }
             } else {
                 r = (nearHit & bit) ? true : r;
-                cur = M.bvh[cur].parent;
+                cur = node_parent(M, cur);
                 depth--;
             }
         }
@@ -256,7 +284,7 @@ __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
 {
     float tm;
     const RayRcp rr = ray_rcp(d);
-    if (!box_hit_rcp(M.bvh[1].b, o, d, rr, BHRT_BIGFLOAT, tm)) return false;
+    if (!box_hit_rcp(node_at(M, 1).b, o, d, rr, BHRT_BIGFLOAT, tm)) return false;
     const float dlen = length(d);
     uint32_t cur = 1;
     int depth = 0;
@@ -264,7 +292,7 @@ __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
     float t_min = BHRT_BIGFLOAT;
     while (true) { // single-loop state machine (measured faster than the phased form for any-hit rays)
         if (desc) {
-            const uint32_t data = M.bvh[cur].data;
+            const uint32_t data = node_data(M, cur);
             if (data & 0x80000000u) {
                 const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
                 float ht = BHRT_BIGFLOAT; // fresh HitInfo per leaf (TriObj.cpp:280)
@@ -278,15 +306,16 @@ __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
             } else {
                 const uint32_t c1 = data & 0x7fffffffu;
                 float t1, t2;
-                bool b1 = box_hit_rcp(M.bvh[c1].b, o, d, rr, BHRT_BIGFLOAT, t1);
-                bool b2 = box_hit_rcp(M.bvh[c1 + 1].b, o, d, rr, BHRT_BIGFLOAT, t2);
+                const NodeRec n1 = node_at(M, c1), n2 = node_at(M, c1 + 1);
+                bool b1 = box_hit_rcp(n1.b, o, d, rr, BHRT_BIGFLOAT, t1);
+                bool b2 = box_hit_rcp(n2.b, o, d, rr, BHRT_BIGFLOAT, t2);
                 if (!b1 && !b2) desc = false;
                 else { depth++; cur = c1; }
             }
         } else {
             if (depth == 0) break;
             if ((cur & 1u) == 0) { cur = cur | 1u; desc = true; } // child1 done -> child2
-            else { cur = M.bvh[cur].parent; depth--; }
+            else { cur = node_parent(M, cur); depth--; }
         }
     }
     return found && t_min > BHRT_TRI_BIAS && t_min < t_max;
@@ -337,12 +366,37 @@ __device__ inline bool plane_hit(V3 p, V3 d, int side, float t_cur, float &t_out
 
 // recursive(&rootNode, ...) (Main.cpp:389-413): nodes in DFS pre-order, "t > hit" rejects so a later
 // equal-t candidate wins.
-__device__ inline void trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit &h)
+// LDS nodelet: the workgroup copies the first BHRT_LDS_NODES nodes (top levels, breadth-first numbering) of the mesh it is
+// about to traverse into LDS.  Uniform control flow is required (every thread of the block reaches the barriers): the
+// scene-graph loop below is uniform — `active` only predicates the per-ray work.
+#define BHRT_LDS_NODES 512 /* 16 KB per workgroup: 9 full levels */
+__device__ inline void stage_nodelet(const DevScene &S, int mesh, bhrt_bvh_node *lds, MeshRef &M)
+{
+    M = mesh_ref(S, mesh);
+    const uint32_t nn = S.meshes[mesh].n_bvh_nodes;
+    const uint32_t cnt = nn < BHRT_LDS_NODES ? nn : BHRT_LDS_NODES;
+    __syncthreads(); // previous mesh's nodelet no longer in use
+    const float4 *src = (const float4 *)M.bvh;
+    float4 *dst = (float4 *)lds;
+    for (uint32_t k = threadIdx.x; k < cnt * 2; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+    M.lds = lds;
+    M.n_lds = cnt;
+}
+
+// lds == nullptr: no staging (any thread may call it alone); otherwise ALL threads of the block must call it together.
+__device__ inline void trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit &h, bool active = true, bhrt_bvh_node *lds = nullptr)
 {
     h.t = BHRT_BIGFLOAT; h.node = -1; h.prim = -1; h.front = 1;
     for (int n = 0; n < S.n_nodes; n++) {
         const int type = S.nodes[n].obj_type;
         if (type == BHRT_OBJ_NONE) continue;
+        MeshRef M;
+        if (type == BHRT_OBJ_MESH) {
+            if (lds) stage_nodelet(S, S.nodes[n].mesh, lds, M);
+            else M = mesh_ref(S, S.nodes[n].mesh);
+        }
+        if (!active) continue;
         V3 lp = o, ld = d;
         local_ray(S, n, lp, ld);
         float t;
@@ -352,7 +406,6 @@ __device__ inline void trace_closest(const DevScene &S, V3 o, V3 d, int side, Hi
         } else if (type == BHRT_OBJ_PLANE) {
             if (plane_hit(lp, ld, side, h.t, t, fr)) { h.t = t; h.node = n; h.prim = -1; h.front = fr; }
         } else {
-            MeshRef M = mesh_ref(S, S.nodes[n].mesh);
             if (mesh_closest(M, lp, ld, side, h.t, h.prim, h.front)) h.node = n;
         }
     }

@@ -160,15 +160,20 @@ __global__ void __launch_bounds__(kBlock) k_camera_rays(DevScene S, PassInfo P, 
 // meta == nullptr: every ray uses `uniform_side` (public bhrt_trace_closest_*)
 __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, RayQueue q, uint32_t n, int uniform_side, HitBuf h)
 {
+    __shared__ bhrt_bvh_node nodelet[BHRT_LDS_NODES]; // top BVH levels of the mesh being traversed (device_trace.h)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]), d = v3(q.dx[i], q.dy[i], q.dz[i]);
-    const uint32_t meta = q.meta ? q.meta[i] : 0u;
+    bool active = i < n;
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
+    uint32_t meta = 0;
+    if (active) {
+        o = v3(q.ox[i], q.oy[i], q.oz[i]); d = v3(q.dx[i], q.dy[i], q.dz[i]);
+        meta = q.meta ? q.meta[i] : 0u;
+    }
     const int side = q.meta ? (int)((meta >> 4) & 3u) : uniform_side;
+    const bool dead = q.meta && (meta & 15u) == RK_DEAD;
     Hit hit;
-    if (q.meta && (meta & 15u) == RK_DEAD) { hit.t = BHRT_BIGFLOAT; hit.node = -1; hit.prim = -1; hit.front = 1; }
-    else trace_closest(S, o, d, side, hit);
-    h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front;
+    trace_closest(S, o, d, side, hit, active && !dead, nodelet); // uniform call: the block stages nodelets together
+    if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; }
 }
 
 // frame == nullptr: visibility goes to vis[i] (public bhrt_trace_shadow_*), else to vis[frame[i]]

@@ -1002,6 +1002,29 @@ int LoadSceneXml(const char *path, FlatScene &out, std::string &err)
         o.off_ft = W.Append(m.ft.data(), m.ft.size() * 4);
         o.off_bvh = W.Append(m.bvh.data(), m.bvh.size() * sizeof(bhrt_bvh_node));
         o.off_elems = W.Append(m.elems.data(), m.elems.size() * 4);
+        { // breadth-first renumbering for the device (children stay adjacent, first child even, like cyBVH.h:281-291)
+            std::vector<bhrt_bvh_node> dn(m.bvh.size());
+            memset(dn.data(), 0, sizeof(bhrt_bvh_node) * dn.size());
+            std::vector<uint32_t> order = {1};     // old ids in BFS order
+            std::vector<uint32_t> newid(m.bvh.size(), 0);
+            newid[1] = 1;
+            uint32_t next = 2;
+            for (size_t k = 0; k < order.size(); k++) {
+                const uint32_t oldn = order[k];
+                const bhrt_bvh_node &src = m.bvh[oldn];
+                bhrt_bvh_node &dst = dn[newid[oldn]];
+                dst = src;
+                dst.parent = src.parent ? newid[src.parent] : 0;
+                if (!(src.data & 0x80000000u)) {
+                    const uint32_t c1 = src.data & 0x7fffffffu;
+                    newid[c1] = next; newid[c1 + 1] = next + 1;
+                    dst.data = next;
+                    next += 2;
+                    order.push_back(c1); order.push_back(c1 + 1);
+                }
+            }
+            o.off_dbvh = W.Append(dn.data(), dn.size() * sizeof(bhrt_bvh_node));
+        }
         std::vector<bhrt_tri> tris(o.nf);
         for (uint32_t f = 0; f < o.nf; f++) {
             memset(&tris[f], 0, sizeof(bhrt_tri));

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 MAGIC = 0x54524842
-VERSION = 5
+VERSION = 6
 BIGFLOAT = np.float32(1.0e30)
 
 OBJ_NONE, OBJ_SPHERE, OBJ_PLANE, OBJ_MESH = 0, 1, 2, 3
@@ -32,7 +32,7 @@ class Mesh(C.Structure):
                 ("n_bvh_nodes", C.c_uint32), ("bvh_depth", C.c_uint32),
                 ("off_v", C.c_uint64), ("off_vn", C.c_uint64), ("off_vt", C.c_uint64),
                 ("off_f", C.c_uint64), ("off_fn", C.c_uint64), ("off_ft", C.c_uint64),
-                ("off_bvh", C.c_uint64), ("off_elems", C.c_uint64), ("off_tris", C.c_uint64), ("off_leaf_tris", C.c_uint64),
+                ("off_bvh", C.c_uint64), ("off_elems", C.c_uint64), ("off_tris", C.c_uint64), ("off_dbvh", C.c_uint64), ("off_leaf_tris", C.c_uint64),
                 ("bound_min", C.c_float * 3), ("bound_max", C.c_float * 3)]
 
 
@@ -114,4 +114,5 @@ class FlatView:
             "bvh_parent": bvh[:, 7].copy(),
             "bvh_raw": bvh,
             "elems": self.np(m.off_elems, m.nf, np.uint32),
+            "dbvh_raw": self.np(m.off_dbvh, m.n_bvh_nodes * 8, np.uint32).reshape(-1, 8),
         }

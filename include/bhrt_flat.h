@@ -20,7 +20,7 @@
 #include <stdint.h>
 
 #define BHRT_FLAT_MAGIC 0x54524842u /* "BHRT" */
-#define BHRT_FLAT_VERSION 5u
+#define BHRT_FLAT_VERSION 6u
 #define BHRT_MAX_NODE_DEPTH 8 /* scene-graph depth below the root the kernels support */
 #define BHRT_BIGFLOAT 1.0e30f  /* Scenes/scene.h:38 */
 
@@ -81,6 +81,9 @@ typedef struct bhrt_mesh {
     uint64_t off_bvh;                  /* bhrt_bvh_node[n_bvh_nodes] */
     uint64_t off_elems;                /* uint32[nf] */
     uint64_t off_tris;                 /* bhrt_tri[nf], indexed by triangle id */
+    uint64_t off_dbvh;                 /* bhrt_bvh_node[n_bvh_nodes]: the SAME tree renumbered breadth-first (root 1, children still adjacent,
+                                          first child even), so the top levels are the lowest ids -> stageable in LDS.  Traversal uses this copy;
+                                          off_bvh keeps cyBVH's own numbering (what the reference's node array looks like). */
     uint64_t off_leaf_tris;            /* bhrt_tri[nf] in BVH leaf order: entry k = triangle elems[k] (one load instead of two dependent ones) */
     float bound_min[3], bound_max[3];  /* cyTriMesh::ComputeBoundingBox */
 } bhrt_mesh;
