@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development aid: all ranks share cuda:0 and the gather goes through gloo on host copies, "
+                         "to rehearse the N > 1 control flow on a one-GPU box (numbers are meaningless)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,12 +120,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if N > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     if rank == 0:
         ensure_assets()
@@ -143,8 +151,12 @@ def main():
     def step():
         st = sc.render_dev(opts, d_rgb.data_ptr(), d_rad.data_ptr())
         if N > 1:
-            BD.gather_framebuffer(d_rad, tile, rank, N)  # RCCL all_gather of the float radiance tiles
-            BD.gather_framebuffer(d_rgb, tile, rank, N)  # and of the RGB8 tiles
+            if args.rehearse_on_one_gpu:
+                BD.gather_framebuffer(d_rad.cpu(), tile, rank, N)
+                BD.gather_framebuffer(d_rgb.cpu(), tile, rank, N)
+            else:
+                BD.gather_framebuffer(d_rad, tile, rank, N)  # RCCL all_gather of the float radiance tiles
+                BD.gather_framebuffer(d_rgb, tile, rank, N)  # and of the RGB8 tiles
         return st
 
     def sync():
@@ -165,10 +177,11 @@ def main():
     elapsed = time.perf_counter() - t0
     rays_local = agg["closest_rays"] + agg["shadow_rays"]
     if N > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        rr = torch.tensor([rays_local, agg["closest_rays"], agg["camera_samples"]], dtype=torch.float64, device=dev)
+        rr = torch.tensor([rays_local, agg["closest_rays"], agg["camera_samples"]], dtype=torch.float64, device=rdev)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         rays_total, closest_total, samples_total = (float(x) for x in rr.tolist())
     else:
