@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(kBlock) k_camera_rays(DevScene S, PassInfo P, 
 
 // ------------------------------------------------------------------------------------------------
 // meta == nullptr: every ray uses `uniform_side` (public bhrt_trace_closest_*)
-__global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, RayQueue q, uint32_t n, int uniform_side, HitBuf h)
+__global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, RayQueue q, uint32_t n, int uniform_side, HitBuf h, RayOrder ord, Counters *cnt)
 {
     __shared__ bhrt_bvh_node nodelet[BHRT_LDS_NODES]; // top BVH levels of the mesh being traversed (device_trace.h)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -174,6 +174,39 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, RayQueue q
     Hit hit;
     trace_closest(S, o, d, side, hit, active && !dead, nodelet); // uniform call: the block stages nodelets together
     if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; }
+    if (!ord.idx) return; // public trace API: no shading order wanted (uniform)
+    // ---- file the ray under its shading class (device_types.h::RayOrder); same predicate as k_shade's `new_frame`
+    uint32_t cls = RC_NONE;
+    if (active && !dead) {
+        const uint32_t kind = meta & 15u;
+        const bool is_hit = hit.node >= 0;
+        bool heavy = false;
+        if (is_hit) {
+            if (kind == RK_CAMERA) heavy = true;
+            else if (kind == RK_GI) heavy = fabsf(hit.t) > BHRT_BIAS;
+            else if (kind == RK_REFR_IN) heavy = hit.front != 0;
+            else heavy = true;
+        }
+        cls = heavy ? RC_HEAVY : ((kind == RK_REFR_IN && is_hit) ? RC_MEDIUM : RC_LIGHT);
+    }
+    const uint32_t lane = __lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t shard = (i >> 10) & (BHRT_ORDER_SHARDS - 1); // 16 consecutive waves share a shard: keeps camera-ray neighbourhoods together
+    const uint64_t m0 = __ballot(cls == RC_HEAVY), m1 = __ballot(cls == RC_MEDIUM), m2 = __ballot(cls == RC_LIGHT);
+    uint32_t base = 0;
+    if (lane < 3) { // lanes 0..2 reserve room for classes 0..2
+        const uint64_t mk = lane == 0 ? m0 : (lane == 1 ? m1 : m2);
+        const uint32_t c = (uint32_t)__popcll(mk);
+        if (c) base = atomicAdd(&cnt->cls[lane][shard].v, c);
+    }
+    // broadcast the three bases with ALL lanes executing the shuffles (a lane-0..2 ray may itself be classless)
+    const uint32_t b0 = __shfl(base, 0), b1 = __shfl(base, 1), b2 = __shfl(base, 2);
+    if (cls != RC_NONE) {
+        const uint64_t mm = cls == RC_HEAVY ? m0 : (cls == RC_MEDIUM ? m1 : m2);
+        const uint32_t pos = (cls == RC_HEAVY ? b0 : (cls == RC_MEDIUM ? b1 : b2)) + (uint32_t)__popcll(mm & lt);
+        if (pos < ord.shard_cap) ord.idx[((size_t)cls * BHRT_ORDER_SHARDS + shard) * ord.shard_cap + pos] = i;
+        else atomicOr(&cnt->overflow, 8u);
+    }
 }
 
 // frame == nullptr: visibility goes to vis[i] (public bhrt_trace_shadow_*), else to vis[frame[i]]
@@ -184,6 +217,20 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(DevScene S, ShadowQueue
     const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]), d = v3(q.dx[i], q.dy[i], q.dz[i]);
     const float v = trace_shadow(S, o, d, q.tmax[i]);
     vis[q.frame ? q.frame[i] : i] = v;
+}
+
+// segment table of the shading order for k_shade (one tiny workgroup per wave step)
+__global__ void k_order_prefix(const Counters *cnt, RayOrder ord)
+{
+    if (threadIdx.x != 0) return;
+    uint32_t start = 0;
+    for (uint32_t s = 0; s < 3 * BHRT_ORDER_SHARDS; s++) {
+        const uint32_t c = cnt->cls[s / BHRT_ORDER_SHARDS][s % BHRT_ORDER_SHARDS].v;
+        ord.seg_start[s] = start;
+        ord.seg_count[s] = c;
+        start += (c + kShadeBlock - 1) / kShadeBlock;
+    }
+    ord.seg_start[3 * BHRT_ORDER_SHARDS] = start;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -323,11 +370,28 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
 }
 
 __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene S, RenderParams R, PassInfo P, RayQueue qin, HitBuf hb, uint32_t n, RayQueue qout,
-                                                   ShadowQueue qs, Frames F, float *samples, Counters *cnt)
+                                                   ShadowQueue qs, Frames F, float *samples, Counters *cnt, RayOrder ord)
 {
     __shared__ BlockAllocLds lds;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool active = i < n;
+    // this workgroup's slice of the shading order: segments (class, shard) in class-major order, each padded to whole
+    // workgroups; seg_start[] (k_order_prefix) is ascending, the segment is the last one starting at or before blockIdx
+    constexpr uint32_t kSegs = 3 * BHRT_ORDER_SHARDS;
+    __shared__ uint32_t s_seg;
+    if (threadIdx.x < 64) {
+        const uint32_t l = threadIdx.x;
+        const uint32_t a = ord.seg_start[l], b = (l + 64 < kSegs) ? ord.seg_start[l + 64] : 0xffffffffu;
+        const uint32_t n_le = (uint32_t)__popcll(__ballot(a <= blockIdx.x)) + (uint32_t)__popcll(__ballot(b <= blockIdx.x));
+        if (l == 0) s_seg = n_le - 1; // seg_start[0] == 0 <= blockIdx always
+    }
+    __syncthreads();
+    const uint32_t seg = s_seg;
+    if (blockIdx.x >= ord.seg_start[kSegs]) return; // uniform per workgroup: beyond the last segment
+    const uint32_t seg_cnt = ord.seg_count[seg];
+    const uint32_t bb = blockIdx.x - ord.seg_start[seg];
+    const uint32_t local = bb * kShadeBlock + threadIdx.x;
+    bool active = local < seg_cnt;
+    const uint32_t i = active ? ord.idx[(size_t)seg * ord.shard_cap + local] : 0u;
+    (void)n;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
     uint32_t owner = 0, meta = 0, ctr = 0;
     Hit hit = {BHRT_BIGFLOAT, -1, -1, 1};
@@ -690,6 +754,9 @@ struct DeviceState {
     uint64_t *d_fcode = nullptr;               // cap_frames
     float *d_ff = nullptr;                     // (3*7 + 2) * cap_frames
     float *d_samples = nullptr;                // 3 * cap_samples
+    uint32_t *d_order = nullptr;               // 3 * BHRT_ORDER_SHARDS * order_shard_cap (shading order, device_types.h::RayOrder)
+    uint32_t order_shard_cap = 0;
+    uint32_t *d_seg = nullptr;                 // seg_start[97] + seg_count[96]
     Counters *d_cnt = nullptr;
     Counters *h_cnt = nullptr; // pinned
     hipStream_t stream = nullptr;
@@ -720,7 +787,7 @@ void DestroyDeviceState(DeviceState *d)
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(d->d_blob); fr(d->d_chain);
     for (int k = 0; k < 2; k++) { fr(d->d_rayf[k]); fr(d->d_rayu[k]); }
-    fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_cnt);
+    fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_seg); fr(d->d_cnt);
     fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr_d2); fr(d->d_scr_idx);
     if (d->h_cnt) (void)hipHostFree(d->h_cnt);
     for (int k = 0; k < 2; k++) if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
@@ -749,7 +816,8 @@ static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, uint32_t frames
     if (D->cap_samples >= cap_samples && D->cap_frames >= cap_samples * frames_per_sample) return BHRT_OK;
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     for (int k = 0; k < 2; k++) { fr(D->d_rayf[k]); fr(D->d_rayu[k]); D->d_rayf[k] = nullptr; D->d_rayu[k] = nullptr; }
-    fr(D->d_hitf); fr(D->d_hiti); fr(D->d_shf); fr(D->d_shu); fr(D->d_fu); fr(D->d_fcode); fr(D->d_ff); fr(D->d_samples);
+    fr(D->d_hitf); fr(D->d_hiti); fr(D->d_shf); fr(D->d_shu); fr(D->d_fu); fr(D->d_fcode); fr(D->d_ff); fr(D->d_samples); fr(D->d_order);
+    D->d_order = nullptr;
     D->d_hitf = nullptr; D->d_hiti = nullptr; D->d_shf = nullptr; D->d_shu = nullptr; D->d_fu = nullptr; D->d_fcode = nullptr; D->d_ff = nullptr; D->d_samples = nullptr;
     D->cap_samples = 0;
     const size_t cr = (size_t)cap_samples * 2, cf = (size_t)cap_samples * frames_per_sample;
@@ -765,6 +833,8 @@ static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, uint32_t frames
     HIP_CHECK(hipMalloc(&D->d_fcode, cf * sizeof(uint64_t)));
     HIP_CHECK(hipMalloc(&D->d_ff, cf * 23 * sizeof(float)));
     HIP_CHECK(hipMalloc(&D->d_samples, (size_t)cap_samples * 3 * sizeof(float)));
+    D->order_shard_cap = (uint32_t)((((cr + 1023) / 1024 + BHRT_ORDER_SHARDS - 1) / BHRT_ORDER_SHARDS) * 1024 + 1024); // rays [1024 g, 1024 g + 1024) file under shard g mod 32
+    HIP_CHECK(hipMalloc(&D->d_order, (size_t)3 * BHRT_ORDER_SHARDS * D->order_shard_cap * sizeof(uint32_t)));
     D->cap_samples = cap_samples; D->cap_rays = (uint32_t)cr; D->cap_frames = (uint32_t)cf;
     if (D->d_ph_frames) { (void)hipFree(D->d_ph_frames); D->d_ph_frames = nullptr; D->ph_frames_cap = 0; }
     return BHRT_OK;
@@ -905,6 +975,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         HitBuf HB; HB.t = D->d_hitf; HB.node = D->d_hiti; HB.prim = D->d_hiti + D->cap_rays; HB.front = D->d_hiti + 2 * (size_t)D->cap_rays;
         ShadowQueue SQ; { float *p = D->d_shf; const size_t c = D->cap_rays; SQ.ox = p; SQ.oy = p + c; SQ.oz = p + 2 * c; SQ.dx = p + 3 * c; SQ.dy = p + 4 * c; SQ.dz = p + 5 * c; SQ.tmax = p + 6 * c; SQ.frame = D->d_shu; }
         Frames F = MakeFrames(D);
+        RayOrder RO = {D->d_order, D->order_shard_cap, D->d_seg, D->d_seg + 3 * BHRT_ORDER_SHARDS + 1};
         HIP_CHECK(hipMemsetAsync(D->d_cnt, 0, sizeof(Counters), D->stream));
         HIP_CHECK(hipMemsetAsync(D->d_samples, 0, (size_t)npx * o.spp * 3 * sizeof(float), D->stream));
         const uint32_t total = npx * (uint32_t)o.spp;
@@ -920,17 +991,18 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         bool overflow = false;
         uint64_t pass_closest = 0;
         while (n_cur > 0) {
+            // reset the per-step counters: next queue, shadow queue, shading-order classes (frames keep counting across steps)
+            HIP_CHECK(hipMemsetAsync(&D->d_cnt->n_next, 0, offsetof(Counters, n_frames), D->stream));
             {
                 Timer t(D, &st->seconds_trace_closest);
-                hipLaunchKernelGGL(k_trace_closest, dim3((n_cur + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, Q[cur], n_cur, 0, HB);
+                hipLaunchKernelGGL(k_trace_closest, dim3((n_cur + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
                 t.Stop();
             }
             st->launches_trace_closest++;
-            // reset the per-step queue counters (frames keep counting across steps)
-            HIP_CHECK(hipMemsetAsync(&D->d_cnt->n_next, 0, 2 * sizeof(uint32_t), D->stream));
+            hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
             {
                 Timer t(D, &st->seconds_shade);
-                hipLaunchKernelGGL(k_shade, dim3((n_cur + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt);
+                hipLaunchKernelGGL(k_shade, dim3((n_cur + kShadeBlock - 1) / kShadeBlock + 3 * BHRT_ORDER_SHARDS), dim3(kShadeBlock), 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt, RO);
                 t.Stop();
             }
             HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, D->stream));
@@ -1040,6 +1112,7 @@ int bhrt_scene_upload(bhrt_scene *scene, int device)
     HIP_CHECK(hipMalloc(&D->d_chain, chain.size() * sizeof(int32_t)));
     HIP_CHECK(hipMemcpy(D->d_chain, chain.data(), chain.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&D->d_cnt, sizeof(Counters)));
+    HIP_CHECK(hipMalloc(&D->d_seg, (6 * BHRT_ORDER_SHARDS + 1) * sizeof(uint32_t)));
     HIP_CHECK(hipHostMalloc(&D->h_cnt, sizeof(Counters)));
     DevScene &S = D->S;
     S.blob = D->d_blob;
@@ -1087,7 +1160,8 @@ int bhrt_trace_closest_dev(bhrt_scene *scene, const float *d_rays_soa, int hit_s
     RayQueue q = MakeRayQueue(const_cast<float *>(d_rays_soa), nullptr, n);
     HitBuf h; h.t = d_out.t; h.node = d_out.node; h.prim = d_out.prim; h.front = d_out.front;
     hipStream_t s = stream ? (hipStream_t)stream : scene->dev->stream;
-    hipLaunchKernelGGL(k_trace_closest, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, q, (uint32_t)n, hit_side, h);
+    RayOrder no_order = {nullptr, 0, nullptr, nullptr};
+    hipLaunchKernelGGL(k_trace_closest, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, q, (uint32_t)n, hit_side, h, no_order, (Counters *)nullptr);
     HIP_CHECK(hipGetLastError());
     if (!stream) HIP_CHECK(hipStreamSynchronize(s));
     return BHRT_OK;
