@@ -77,17 +77,15 @@ struct Frames {
 #define BHRT_ORDER_SHARDS 32
 
 struct Counters {
-    // zeroed at the start of every wave step
-    uint32_t n_next;    // rays pushed to the next closest-hit queue
-    uint32_t n_shadow;  // rays pushed to the shadow queue
-    uint32_t pad0[30];  // the class counters below start on their own 128-byte line
+    // first 128-byte line: everything the host reads back after a wave step
+    uint32_t n_next;    // rays pushed to the next closest-hit queue   (zeroed by k_order_prefix before each k_shade)
+    uint32_t n_shadow;  // rays pushed to the shadow queue             (same)
+    uint32_t n_frames;  // frames allocated so far in this pass
+    uint32_t overflow;  // set when a capacity was exceeded
+    uint32_t pad0[28];
     // traced rays sorted for shading: class x shard element counts (see RayOrder).  One counter per 128-byte line:
     // atomics to different words of ONE line still serialise in L2 (measured: 196 k atomics -> +1.7 ms).
     struct alignas(128) Line { uint32_t v; uint32_t pad[31]; } cls[3][BHRT_ORDER_SHARDS];
-    // running over the whole pass
-    uint32_t n_frames;  // frames allocated so far in this pass
-    uint32_t overflow;  // set when a capacity was exceeded
-    uint32_t pad[4];
 };
 
 // Shading order.  k_trace_closest files every traced ray under one of three classes, so that a k_shade workgroup

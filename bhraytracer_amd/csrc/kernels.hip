@@ -220,12 +220,18 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(DevScene S, ShadowQueue
 }
 
 // segment table of the shading order for k_shade (one tiny workgroup per wave step)
-__global__ void k_order_prefix(const Counters *cnt, RayOrder ord)
+// Runs between the trace kernel and k_shade of a wave step; also puts the per-step counters back to zero (class counters
+// for the next trace, queue counters for the k_shade that follows), which saves a memset per step.
+__global__ void k_order_prefix(Counters *cnt, RayOrder ord)
 {
     if (threadIdx.x != 0) return;
+    cnt->n_next = 0;
+    cnt->n_shadow = 0;
     uint32_t start = 0;
     for (uint32_t s = 0; s < 3 * BHRT_ORDER_SHARDS; s++) {
-        const uint32_t c = cnt->cls[s / BHRT_ORDER_SHARDS][s % BHRT_ORDER_SHARDS].v;
+        uint32_t c = cnt->cls[s / BHRT_ORDER_SHARDS][s % BHRT_ORDER_SHARDS].v;
+        cnt->cls[s / BHRT_ORDER_SHARDS][s % BHRT_ORDER_SHARDS].v = 0;
+        if (c > ord.shard_cap) c = ord.shard_cap; // the writer flagged the overflow; never index past the segment
         ord.seg_start[s] = start;
         ord.seg_count[s] = c;
         start += (c + kShadeBlock - 1) / kShadeBlock;
@@ -991,8 +997,6 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         bool overflow = false;
         uint64_t pass_closest = 0;
         while (n_cur > 0) {
-            // reset the per-step counters: next queue, shadow queue, shading-order classes (frames keep counting across steps)
-            HIP_CHECK(hipMemsetAsync(&D->d_cnt->n_next, 0, offsetof(Counters, n_frames), D->stream));
             {
                 Timer t(D, &st->seconds_trace_closest);
                 hipLaunchKernelGGL(k_trace_closest, dim3((n_cur + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
@@ -1005,7 +1009,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 hipLaunchKernelGGL(k_shade, dim3((n_cur + kShadeBlock - 1) / kShadeBlock + 3 * BHRT_ORDER_SHARDS), dim3(kShadeBlock), 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt, RO);
                 t.Stop();
             }
-            HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, D->stream));
+            HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, 16, hipMemcpyDeviceToHost, D->stream)); // n_next, n_shadow, n_frames, overflow
             HIP_CHECK(hipStreamSynchronize(D->stream));
             FlushTimers(D);
             if (D->h_cnt->overflow) { overflow = true; break; }
