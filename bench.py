@@ -30,6 +30,8 @@ WORKLOADS = {
     "c1": ("tests/scenes/c1_sphere_plane.xml", 640, 480, 1, -1),
     "c2": ("tests/scenes/c2_glass.xml", 1920, 1080, 16, 3),
     "c3": ("tests/scenes/c3_mesh.xml", 1920, 1080, 64, 3),
+    # BASELINE config 5: caustic photon map, 1 M photons, k = 1000, r = 0.5 (photon build timed separately, see "photon_build_s")
+    "c5": ("tests/scenes/c5_caustics_hd.xml", 1920, 1080, 64, 3),
 }
 BYTES_PER_CLOSEST_RAY = 56  # 32 B ray read + 24 B hit write
 BYTES_PER_SHADOW_RAY = 36   # 32 B read + 4 B visibility write
@@ -101,6 +103,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--photons", type=int, default=1000000, help="photon budget of workload c5 (MAX_CausticPhotonCount, Main.cpp:53)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: all ranks share cuda:0 and the gather goes through gloo on host copies, "
                          "to rehearse the N > 1 control flow on a one-GPU box (numbers are meaningless)")
@@ -144,6 +147,13 @@ def main():
     spp = spp1 * N  # weak scaling: per-GPU sample count is fixed
     tile = 32
     opts = B.default_opts(spp=spp, gi_bounces=gi, internal_bounces=16, seed=0, rank=rank, world_size=N, tile_size=tile)
+    photon_build_s = None
+    if args.workload == "c5":
+        t0 = time.perf_counter()
+        n_ph = sc.photon_build(opts, args.photons)  # every rank builds the same map (emission is keyed by emission index)
+        torch.cuda.synchronize()
+        photon_build_s = time.perf_counter() - t0
+        opts.photon_map = 1
 
     d_rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
     d_rad = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
@@ -225,6 +235,7 @@ def main():
                                    f"internal bounces 16, keyed RNG seed 0, {tile}x{tile} interleaved tiles over {N} GPU(s)",
                        "rays_per_frame": rays_total / args.steps, "camera_samples_per_frame": samples_total / args.steps,
                        "framebuffer_gather": "rccl all_gather (float radiance + rgb8 tiles)" if N > 1 else "none"},
+            "photon_build_s": photon_build_s, "photon_gather_s_per_frame": (agg.get("reserved0", 0.0) / args.steps) if photon_build_s else None,
             "kernel_seconds": k_times,
             "kernels": per_kernel,
             "wave_steps_per_frame": agg["wave_iterations"] / args.steps,

@@ -44,7 +44,9 @@ class Stats(C.Structure):
                 ("reserved", C.c_double * 4)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        d["reserved0"] = self.reserved[0]  # seconds in the photon gather kernel
+        return d
 
 
 class Hits(C.Structure):
