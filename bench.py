@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--samples-per-pass", type=int, default=0, help="camera samples in flight per wavefront pass (0 = library default)")
     ap.add_argument("--photons", type=int, default=1000000, help="photon budget of workload c5 (MAX_CausticPhotonCount, Main.cpp:53)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: all ranks share cuda:0 and the gather goes through gloo on host copies, "
@@ -147,6 +148,7 @@ def main():
     spp = spp1 * N  # weak scaling: per-GPU sample count is fixed
     tile = 32
     opts = B.default_opts(spp=spp, gi_bounces=gi, internal_bounces=16, seed=0, rank=rank, world_size=N, tile_size=tile)
+    opts.samples_per_pass = args.samples_per_pass
     photon_build_s = None
     if args.workload == "c5":
         t0 = time.perf_counter()

@@ -12,7 +12,7 @@ import numpy as np
 from .flat import FlatView
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbhrt.so")
+LIB_PATH = os.environ.get("BHRT_LIB") or os.path.join(_HERE, "libbhrt.so")  # BHRT_LIB: load another build of the same ABI
 
 SIDE_FRONT, SIDE_BACK, SIDE_BOTH = 1, 2, 3
 

@@ -77,16 +77,17 @@ struct Frames {
 #define BHRT_ORDER_SHARDS 32
 
 struct Counters {
-    // first 128-byte line: everything the host reads back after a wave step
-    uint32_t n_next;    // rays pushed to the next closest-hit queue   (zeroed by k_order_prefix before each k_shade)
-    uint32_t n_shadow;  // rays pushed to the shadow queue             (same)
-    uint32_t n_frames;  // frames allocated so far in this pass
-    uint32_t overflow;  // set when a capacity was exceeded
-    uint32_t pad0[28];
-    // traced rays sorted for shading: class x shard element counts (see RayOrder).  One counter per 128-byte line:
-    // atomics to different words of ONE line still serialise in L2 (measured: 196 k atomics -> +1.7 ms).
-    struct alignas(128) Line { uint32_t v; uint32_t pad[31]; } cls[3][BHRT_ORDER_SHARDS];
+    // One counter per 128-byte line: atomics to different words of ONE line still serialise in L2
+    // (measured: 196 k atomics on one line -> +1.7 ms).  The host reads back the first four lines after a wave step.
+    struct alignas(128) Line { uint32_t v; uint32_t pad[31]; };
+    Line n_next;    // rays pushed to the next closest-hit queue   (zeroed by k_order_prefix before each k_shade)
+    Line n_shadow;  // rays pushed to the shadow queue             (same)
+    Line n_frames;  // frames allocated so far in this pass
+    Line overflow;  // set when a capacity was exceeded
+    // traced rays sorted for shading: class x shard element counts (see RayOrder)
+    Line cls[3][BHRT_ORDER_SHARDS];
 };
+#define BHRT_COUNTERS_HOST_BYTES (4 * 128)
 
 // Shading order.  k_trace_closest files every traced ray under one of three classes, so that a k_shade workgroup
 // only holds rays of one class (GI rays are incoherent: without this, nearly every wave mixes a few expensive

@@ -70,7 +70,10 @@ __device__ inline bool pixel_of(const PassInfo &P, uint32_t q, int &i, int &j)
 // ONE atomic per workgroup and queue.  (One atomic per wave was the bottleneck of the first version: a
 // single word takes ~88 atomics/us on MI355X, and a 16 M-lane launch has 262 k waves.)
 // All threads of the block must call it (convergent call sites only).  kShadeBlock threads per block.
-constexpr int kShadeBlock = 1024;
+#ifndef BHRT_SHADE_BLOCK
+#define BHRT_SHADE_BLOCK 1024
+#endif
+constexpr int kShadeBlock = BHRT_SHADE_BLOCK;
 constexpr int kShadeWaves = kShadeBlock / 64;
 
 struct BlockAllocLds {
@@ -205,7 +208,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, RayQueue q
         const uint64_t mm = cls == RC_HEAVY ? m0 : (cls == RC_MEDIUM ? m1 : m2);
         const uint32_t pos = (cls == RC_HEAVY ? b0 : (cls == RC_MEDIUM ? b1 : b2)) + (uint32_t)__popcll(mm & lt);
         if (pos < ord.shard_cap) ord.idx[((size_t)cls * BHRT_ORDER_SHARDS + shard) * ord.shard_cap + pos] = i;
-        else atomicOr(&cnt->overflow, 8u);
+        else atomicOr(&cnt->overflow.v, 8u);
     }
 }
 
@@ -222,21 +225,30 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(DevScene S, ShadowQueue
 // segment table of the shading order for k_shade (one tiny workgroup per wave step)
 // Runs between the trace kernel and k_shade of a wave step; also puts the per-step counters back to zero (class counters
 // for the next trace, queue counters for the k_shade that follows), which saves a memset per step.
-__global__ void k_order_prefix(Counters *cnt, RayOrder ord)
+__global__ void __launch_bounds__(128) k_order_prefix(Counters *cnt, RayOrder ord)
 {
-    if (threadIdx.x != 0) return;
-    cnt->n_next = 0;
-    cnt->n_shadow = 0;
-    uint32_t start = 0;
-    for (uint32_t s = 0; s < 3 * BHRT_ORDER_SHARDS; s++) {
-        uint32_t c = cnt->cls[s / BHRT_ORDER_SHARDS][s % BHRT_ORDER_SHARDS].v;
+    // 96 segments (class-major), one lane each: read + reset its counter, then an exclusive scan of the segments' workgroup counts
+    constexpr uint32_t kSegs = 3 * BHRT_ORDER_SHARDS;
+    __shared__ uint32_t s_blocks[128];
+    const uint32_t s = threadIdx.x;
+    uint32_t c = 0;
+    if (s < kSegs) {
+        c = cnt->cls[s / BHRT_ORDER_SHARDS][s % BHRT_ORDER_SHARDS].v;
         cnt->cls[s / BHRT_ORDER_SHARDS][s % BHRT_ORDER_SHARDS].v = 0;
         if (c > ord.shard_cap) c = ord.shard_cap; // the writer flagged the overflow; never index past the segment
-        ord.seg_start[s] = start;
-        ord.seg_count[s] = c;
-        start += (c + kShadeBlock - 1) / kShadeBlock;
     }
-    ord.seg_start[3 * BHRT_ORDER_SHARDS] = start;
+    if (s == 0) { cnt->n_next.v = 0; cnt->n_shadow.v = 0; }
+    s_blocks[s] = (c + kShadeBlock - 1) / kShadeBlock;
+    __syncthreads();
+    for (uint32_t off = 1; off < 128; off <<= 1) { // Hillis-Steele inclusive scan
+        const uint32_t add = s >= off ? s_blocks[s - off] : 0u;
+        __syncthreads();
+        s_blocks[s] += add;
+        __syncthreads();
+    }
+    const uint32_t incl = s_blocks[s], excl = incl - (c + kShadeBlock - 1) / kShadeBlock;
+    if (s < kSegs) { ord.seg_start[s] = excl; ord.seg_count[s] = c; }
+    if (s == kSegs - 1) ord.seg_start[kSegs] = incl;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -422,8 +434,8 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene S, RenderParams 
         else new_frame = true;                                        // RK_REFR_OUT, MtlBlinn.cpp:527-533
     }
     uint32_t f, u0, u1, u2;
-    block_alloc3(lds, &cnt->n_frames, new_frame ? 1u : 0u, 0u, nullptr, 0u, nullptr, 0u, f, u0, u1, u2);
-    if (new_frame && f >= R.cap_frames) { atomicOr(&cnt->overflow, 1u); new_frame = false; }
+    block_alloc3(lds, &cnt->n_frames.v, new_frame ? 1u : 0u, 0u, nullptr, 0u, nullptr, 0u, f, u0, u1, u2);
+    if (new_frame && f >= R.cap_frames) { atomicOr(&cnt->overflow.v, 1u); new_frame = false; }
 
     ShadeOut so;
     so.has_refr = so.has_gi = so.has_shadow = false;
@@ -555,20 +567,20 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene S, RenderParams 
 
     // ---- convergent pushes
     uint32_t r0, r1, s0;
-    block_alloc3(lds, &cnt->n_next, so.has_refr ? 1u : 0u, so.has_gi ? 1u : 0u, &cnt->n_shadow, so.has_shadow ? 1u : 0u, nullptr, 0u, r0, r1, s0, u2);
+    block_alloc3(lds, &cnt->n_next.v, so.has_refr ? 1u : 0u, so.has_gi ? 1u : 0u, &cnt->n_shadow.v, so.has_shadow ? 1u : 0u, nullptr, 0u, r0, r1, s0, u2);
     if (so.has_refr) {
         if (r0 < R.cap_rays) put_ray(qout, r0, so.ro, so.rd, ray_owner, so.rmeta, so.rctr);
-        else atomicOr(&cnt->overflow, 2u);
+        else atomicOr(&cnt->overflow.v, 2u);
     }
     if (so.has_gi) {
         if (r1 < R.cap_rays) put_ray(qout, r1, so.go, so.gd, ray_owner, make_meta(RK_GI, BHRT_HIT_FRONT, 0), 0);
-        else atomicOr(&cnt->overflow, 2u);
+        else atomicOr(&cnt->overflow.v, 2u);
     }
     if (so.has_shadow) {
         if (s0 < R.cap_shadow) {
             qs.ox[s0] = so.so.x; qs.oy[s0] = so.so.y; qs.oz[s0] = so.so.z; qs.dx[s0] = so.sd.x; qs.dy[s0] = so.sd.y; qs.dz[s0] = so.sd.z;
             qs.tmax[s0] = so.stmax; qs.frame[s0] = ray_owner;
-        } else atomicOr(&cnt->overflow, 4u);
+        } else atomicOr(&cnt->overflow.v, 4u);
     }
 }
 
@@ -949,7 +961,10 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
     const uint32_t owned_tiles = n_tiles > (uint32_t)o.rank ? (n_tiles - (uint32_t)o.rank + (uint32_t)world - 1) / (uint32_t)world : 0;
     const uint64_t owned_pixels = (uint64_t)owned_tiles * tile * tile;
 
-    uint32_t pass_samples = o.samples_per_pass > 0 ? (uint32_t)o.samples_per_pass : (1u << 24); // sized for 288 GB of HBM: few, large passes
+    // Sized for 288 GB of HBM: few, large passes (every pass ends in a tail of nearly empty wavefront steps, so fewer passes = fewer
+    // tails).  ~1 KB of wavefront state per camera sample -> the default of 2^26 samples in flight takes ~65 GB.
+    uint32_t pass_samples = o.samples_per_pass > 0 ? (uint32_t)o.samples_per_pass : (1u << 26);
+    pass_samples = (uint32_t)std::min<uint64_t>(pass_samples, std::max<uint64_t>(owned_pixels * (uint64_t)o.spp, 1)); // never more than this render needs
     if (pass_samples < (uint32_t)o.spp) pass_samples = (uint32_t)o.spp;
     const uint32_t frames_per_sample = 6; // Shade() frames per camera sample; an overflow halves the pass and retries
     RenderParams R;
@@ -1003,40 +1018,40 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 t.Stop();
             }
             st->launches_trace_closest++;
-            hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
+            hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(128), 0, D->stream, D->d_cnt, RO);
             {
                 Timer t(D, &st->seconds_shade);
                 hipLaunchKernelGGL(k_shade, dim3((n_cur + kShadeBlock - 1) / kShadeBlock + 3 * BHRT_ORDER_SHARDS), dim3(kShadeBlock), 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt, RO);
                 t.Stop();
             }
-            HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, 16, hipMemcpyDeviceToHost, D->stream)); // n_next, n_shadow, n_frames, overflow
+            HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, BHRT_COUNTERS_HOST_BYTES, hipMemcpyDeviceToHost, D->stream)); // n_next, n_shadow, n_frames, overflow
             HIP_CHECK(hipStreamSynchronize(D->stream));
             FlushTimers(D);
-            if (D->h_cnt->overflow) { overflow = true; break; }
+            if (D->h_cnt->overflow.v) { overflow = true; break; }
             if (first_step) { // camera step: dead rays of edge tiles are not rays
                 const uint64_t valid_px = CountValidPixels(P, npx);
                 pass_closest = valid_px * (uint64_t)o.spp;
                 st->camera_samples += pass_closest;
                 first_step = false;
             } else pass_closest += n_cur;
-            const uint32_t n_sh = D->h_cnt->n_shadow;
+            const uint32_t n_sh = D->h_cnt->n_shadow.v;
             if (n_sh) {
                 Timer t(D, &st->seconds_trace_shadow);
                 hipLaunchKernelGGL(k_trace_shadow, dim3((n_sh + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, SQ, n_sh, F.vis);
                 t.Stop();
                 st->shadow_rays += n_sh; st->launches_trace_shadow++;
             }
-            if (o.photon_map && D->h_cnt->n_frames > frame_marks.back()) { // caustic term of the frames opened in this step
+            if (o.photon_map && D->h_cnt->n_frames.v > frame_marks.back()) { // caustic term of the frames opened in this step
                 Timer t(D, &st->reserved[0]);
-                for (uint32_t fb = frame_marks.back(); fb < D->h_cnt->n_frames; fb += D->scr_lanes) {
-                    const uint32_t fe = std::min<uint32_t>(D->h_cnt->n_frames, fb + D->scr_lanes);
+                for (uint32_t fb = frame_marks.back(); fb < D->h_cnt->n_frames.v; fb += D->scr_lanes) {
+                    const uint32_t fe = std::min<uint32_t>(D->h_cnt->n_frames.v, fb + D->scr_lanes);
                     hipLaunchKernelGGL(k_photon_gather_frames, dim3((fe - fb + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, F, fb, fe, D->d_photons, (int)D->n_photons,
                                        (int)D->n_photons / 2 - 1, 0.5f /* MAX_Area, MtlBlinn.cpp:29 */, D->d_scr_d2, D->d_scr_idx, (size_t)D->scr_lanes, D->S.materials);
                 }
                 t.Stop();
             }
-            frame_marks.push_back(D->h_cnt->n_frames);
-            n_cur = D->h_cnt->n_next;
+            frame_marks.push_back(D->h_cnt->n_frames.v);
+            n_cur = D->h_cnt->n_next.v;
             cur ^= 1;
             st->wave_iterations++;
         }
@@ -1047,7 +1062,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             pass_limit = std::max<uint32_t>((uint32_t)o.spp, pass_limit / 2);
             continue;
         }
-        st->shade_calls += D->h_cnt->n_frames;
+        st->shade_calls += D->h_cnt->n_frames.v;
         st->closest_rays += pass_closest;
         {
             Timer t(D, &st->seconds_other);
