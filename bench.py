@@ -238,6 +238,9 @@ def main():
                        "rays_per_frame": rays_total / args.steps, "camera_samples_per_frame": samples_total / args.steps,
                        "framebuffer_gather": "rccl all_gather (float radiance + rgb8 tiles)" if N > 1 else "none"},
             "photon_build_s": photon_build_s, "photon_gather_s_per_frame": (agg.get("reserved0", 0.0) / args.steps) if photon_build_s else None,
+            "photon_heap_pass_s_per_frame": (agg.get("reserved1", 0.0) / args.steps) if photon_build_s else None,
+            "photon_heap_queries_per_frame": (agg.get("reserved2", 0.0) / args.steps) if photon_build_s else None,
+            "photon_wave_queries_per_frame": (agg.get("reserved3", 0.0) / args.steps) if photon_build_s else None,
             "kernel_seconds": k_times,
             "kernels": per_kernel,
             "wave_steps_per_frame": agg["wave_iterations"] / args.steps,

@@ -45,7 +45,10 @@ class Stats(C.Structure):
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
-        d["reserved0"] = self.reserved[0]  # seconds in the photon gather kernel
+        d["reserved0"] = self.reserved[0]  # seconds in the photon gather
+        d["reserved1"] = self.reserved[1]  # ... of which in the candidate-heap pass
+        d["reserved2"] = self.reserved[2]  # queries that needed the candidate heap
+        d["reserved3"] = self.reserved[3]  # queries walked by a whole wave
         return d
 
 

@@ -191,108 +191,63 @@ __device__ inline uint32_t emit_photon_path(const DevScene &S, uint32_t seed, ui
     return stored;
 }
 
-// Exact replay of EstimateIrradiance<1000> + LocatePhotons for one query.  photons[1..n] balanced (heap order),
-// half = n/2 - 1 (cyPhotonMap.h:257, Q11).  cd2 / cidx: this lane's scratch columns, element k at [k * stride].
-__device__ inline bool photon_estimate(const DPhoton *photons, int n, int half, V3 pos, V3 normal, float radius, float *cd2, uint32_t *cidx,
-                                       size_t stride, V3 &irrad, V3 &direction)
-{
-    irrad = v3(0, 0, 0);
-    direction = v3(0, 0, 0);
-    if (n <= 0) return false;
-    float d2max = radius * radius; // np.dist2[0]
-    int found = 0;
-    bool heap = false;
-    V3 sumI = v3(0, 0, 0), sumD = v3(0, 0, 0); // running sums, valid while the list is still in insertion order
-    int idx = 1;
+// ---- gather ------------------------------------------------------------------------------------------------------
+// Device copy of the balanced map, split by use: the walk reads only `hot` (position + split axis, one 16-byte load
+// per visited node); an accepted photon adds two more 16-byte loads from `cold` (direction, power), both decoded
+// once by k_photon_expand with the reference's own arithmetic (GetDirection's integer square root, Color24::ToColor).
+struct PhotonMapDev {
+    const float4 *hot;  // [n+1]: pos.xyz, w = bits of (planeAndDirZ & 3)
+    const float4 *cold; // [2*(n+1)]: {dir.xyz, power}, {power * color.rgb, 0}
+    int n, half;        // photons[1..n] in heap order; half = n/2 - 1 (cyPhotonMap.h:257)
+    float lo[3], hi[3]; // bounds of the photon positions
+};
+
+struct PhotonWalk { // stackless walk over the balanced kd-tree in the order of LocatePhotons (cyPhotonMap.h:421-498)
+    int idx = 1, from = 0;
     bool desc = true;
-    int from = 0;
+};
+// Advances to the next node whose own photon is due (its hot record in `rec`); false when the walk is over.
+// d2max is the CURRENT squared radius.
+__device__ inline bool photon_walk_next(const PhotonMapDev &M, PhotonWalk &w, V3 pos, float d2max, int &node, float4 &rec)
+{
     while (true) {
-        int node_to_process = 0;
-        if (desc) {
-            if (idx < half) {
-                const DPhoton &p = photons[idx];
-                const int axis = p.planeAndDirZ & 0x3;
-                const float dist = (axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z)) - p.pos[axis];
-                idx = dist > 0 ? 2 * idx + 1 : 2 * idx;
+        if (w.desc) {
+            const float4 h = M.hot[w.idx];
+            if (w.idx < M.half) {
+                const int axis = (int)__float_as_uint(h.w);
+                const float dist = (axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z)) - (axis == 0 ? h.x : (axis == 1 ? h.y : h.z));
+                w.idx = dist > 0 ? 2 * w.idx + 1 : 2 * w.idx;
                 continue;
             }
-            node_to_process = idx;
+            node = w.idx;
+            rec = h;
         } else {
-            if (from == 1) break;
-            const int par = from >> 1;
-            const DPhoton &p = photons[par];
-            const int axis = p.planeAndDirZ & 0x3;
-            const float dist = (axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z)) - p.pos[axis];
+            if (w.from == 1) return false;
+            const int par = w.from >> 1;
+            const float4 h = M.hot[par];
+            const int axis = (int)__float_as_uint(h.w);
+            const float dist = (axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z)) - (axis == 0 ? h.x : (axis == 1 ? h.y : h.z));
             const int firstc = dist > 0 ? 2 * par + 1 : 2 * par;
-            if (from == firstc && dist * dist < d2max) {
-                idx = firstc ^ 1;
-                desc = true;
+            if (w.from == firstc && dist * dist < d2max) {
+                w.idx = firstc ^ 1;
+                w.desc = true;
                 continue;
             }
-            node_to_process = par;
+            node = par;
+            rec = h;
         }
-        { // the node's own photon, cyPhotonMap.h:439-497
-            const DPhoton p = photons[node_to_process];
-            V3 dif = ld3(p.pos) - pos;
-            float dist2 = length_sq(dif);
-            if (dist2 < d2max) {
-                V3 pd = photon_direction(p);
-                if (!(dot(pd, normal) >= 0)) {
-                    if (found < BHRT_PHOTON_K) {
-                        found++;
-                        cd2[(size_t)found * stride] = dist2;
-                        cidx[(size_t)found * stride] = (uint32_t)node_to_process;
-                        sumI = sumI + 1.f * photon_power(p);
-                        sumD = sumD + pd * (1.f * p.power);
-                        if (found == BHRT_PHOTON_K) { // build the max-heap
-                            heap = true;
-                            const int half_found = found >> 1;
-                            for (int k = half_found; k >= 1; k--) {
-                                int parent = k;
-                                const uint32_t tp = cidx[(size_t)k * stride];
-                                const float td2 = cd2[(size_t)k * stride];
-                                while (parent <= half_found) {
-                                    int j = parent + parent;
-                                    if (j < found && cd2[(size_t)j * stride] < cd2[(size_t)(j + 1) * stride]) j++;
-                                    if (td2 >= cd2[(size_t)j * stride]) break;
-                                    cd2[(size_t)parent * stride] = cd2[(size_t)j * stride];
-                                    cidx[(size_t)parent * stride] = cidx[(size_t)j * stride];
-                                    parent = j;
-                                }
-                                cidx[(size_t)parent * stride] = tp;
-                                cd2[(size_t)parent * stride] = td2;
-                            }
-                        }
-                    } else {
-                        int parent = 1, j = 2;
-                        while (j <= found) {
-                            if (j < found && cd2[(size_t)j * stride] < cd2[(size_t)(j + 1) * stride]) j++;
-                            if (dist2 > cd2[(size_t)j * stride]) break;
-                            cd2[(size_t)parent * stride] = cd2[(size_t)j * stride];
-                            cidx[(size_t)parent * stride] = cidx[(size_t)j * stride];
-                            parent = j;
-                            j <<= 1;
-                        }
-                        cidx[(size_t)parent * stride] = (uint32_t)node_to_process;
-                        cd2[(size_t)parent * stride] = dist2;
-                        d2max = cd2[(size_t)1 * stride];
-                    }
-                }
-            }
-        }
-        from = node_to_process;
-        desc = false;
+        w.from = node;
+        w.desc = false;
+        return true;
     }
-    if (found == 0) return false;
-    if (heap) { // the list was reordered: sum in heap-array order like cyPhotonMap.h:353-365
-        sumI = v3(0, 0, 0);
-        sumD = v3(0, 0, 0);
-        for (int i = 1; i <= found; i++) {
-            const DPhoton p = photons[cidx[(size_t)i * stride]];
-            sumI = sumI + 1.f * photon_power(p);
-            sumD = sumD + photon_direction(p) * (1.f * p.power);
-        }
-    }
+}
+__device__ inline bool photon_outside_bounds(const PhotonMapDev &M, V3 pos, float radius)
+{
+    const float r = radius * 1.001f + 1e-6f; // a query farther than this from the photons' box along one axis cannot accept any photon
+    return pos.x < M.lo[0] - r || pos.x > M.hi[0] + r || pos.y < M.lo[1] - r || pos.y > M.hi[1] + r || pos.z < M.lo[2] - r || pos.z > M.hi[2] + r;
+}
+__device__ inline void photon_finish(V3 sumI, V3 sumD, float d2max, V3 &irrad, V3 &direction) // cyPhotonMap.h:366-381
+{
     const float area = (float)M_PI * d2max;
     if (area > 0) {
         const float one_over_area = 1.0f / area;
@@ -300,6 +255,226 @@ __device__ inline bool photon_estimate(const DPhoton *photons, int n, int half, 
     }
     irrad = sumI;
     direction = sumD / length(sumD);
+}
+
+// EstimateIrradiance<1000> for a query that meets fewer than 1000 photons: the candidate list never becomes a heap, so
+// the sums run in walk order and no list has to be kept.  Returns 0 = no photon, 1 = done, 2 = the 1000th photon was
+// met: the caller redoes this query with photon_estimate_heap (the sums then run in heap-array order); 3 = more than
+// `budget` photons visited without an answer: the caller hands the query to a whole wave (k_photon_gather_wave), so
+// that one lane's long walk (a dense cluster inside the radius, most of it rejected) does not hold up its launch.
+__device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 normal, float radius, int budget, V3 &irrad, V3 &direction)
+{
+    irrad = v3(0, 0, 0);
+    direction = v3(0, 0, 0);
+    if (M.n <= 0 || photon_outside_bounds(M, pos, radius)) return 0;
+    const float d2max = radius * radius;
+    int found = 0;
+    V3 sumI = v3(0, 0, 0), sumD = v3(0, 0, 0);
+    PhotonWalk w;
+    int node;
+    float4 h;
+    while (photon_walk_next(M, w, pos, d2max, node, h)) {
+        if (--budget < 0) return 3;
+        const float dist2 = length_sq(v3(h.x, h.y, h.z) - pos);
+        if (dist2 < d2max) {
+            const float4 c0 = M.cold[2 * (size_t)node];
+            const V3 pd = v3(c0.x, c0.y, c0.z);
+            if (!(dot(pd, normal) >= 0)) {
+                if (++found == BHRT_PHOTON_K) return 2;
+                const float4 c1 = M.cold[2 * (size_t)node + 1];
+                sumI = sumI + 1.f * v3(c1.x, c1.y, c1.z);
+                sumD = sumD + pd * (1.f * c0.w);
+            }
+        }
+    }
+    if (found == 0) return 0;
+    photon_finish(sumI, sumD, d2max, irrad, direction);
+    return 1;
+}
+
+// photon_estimate_fast by a whole wave (blockDim = 64).  Without the candidate heap the radius never shrinks, so the
+// SET of visited nodes does not depend on the visiting order: the wave expands the walk breadth-wise from an LDS
+// work stack (64 nodes per round), collects the accepted photons, and puts them back in walk order afterwards — the
+// walk visits near child, far child, then the node itself, so a node's rank is the string of its path digits
+// (0 = near, 1 = far) closed by a 2, compared left to right.  Then one lane adds them up in that order.
+// Returns 0 / 1 like photon_estimate_fast, or 2 = met 1000 photons (heap pass).  All 64 lanes must call it.
+#define BHRT_WAVE_STACK 2048
+struct WaveGatherLds {
+    uint32_t stack[BHRT_WAVE_STACK];
+    unsigned long long key[1024];
+    uint32_t node[1024];
+    float val[7][64]; // staging of 64 photons' cold data for the ordered sum
+};
+__device__ inline unsigned long long photon_walk_rank(const PhotonMapDev &M, V3 pos, uint32_t node)
+{
+    const int depth = 31 - __clz((int)node);
+    unsigned long long key = 0;
+    for (int i = 0; i < depth; i++) { // ancestor at depth i and the path's child below it
+        const uint32_t a = node >> (depth - i), c = node >> (depth - i - 1);
+        const float4 h = M.hot[a];
+        const int axis = (int)__float_as_uint(h.w);
+        const float dist = (axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z)) - (axis == 0 ? h.x : (axis == 1 ? h.y : h.z));
+        const uint32_t nearc = dist > 0 ? 2 * a + 1 : 2 * a;
+        key |= (unsigned long long)(c == nearc ? 0u : 1u) << (62 - 2 * i);
+    }
+    return key | (2ull << (62 - 2 * depth));
+}
+__device__ inline int photon_estimate_wave(const PhotonMapDev &M, WaveGatherLds &L, V3 pos, V3 normal, float radius, V3 &irrad, V3 &direction)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const float d2max = radius * radius;
+    irrad = v3(0, 0, 0);
+    direction = v3(0, 0, 0);
+    if (M.n <= 0) return 0;
+    uint32_t top = 1, n_acc = 0;
+    if (lane == 0) L.stack[0] = 1;
+    __syncthreads();
+    while (top > 0) {
+        const uint32_t take = top < 64u ? top : 64u;
+        top -= take;
+        bool push_near = false, push_far = false, accept = false;
+        uint32_t nearc = 0, me = 0;
+        if (lane < take) {
+            me = L.stack[top + lane];
+            const float4 h = M.hot[me];
+            if ((int)me < M.half) {
+                const int axis = (int)__float_as_uint(h.w);
+                const float dist = (axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z)) - (axis == 0 ? h.x : (axis == 1 ? h.y : h.z));
+                nearc = dist > 0 ? 2 * me + 1 : 2 * me;
+                push_near = true;
+                push_far = dist * dist < d2max;
+            }
+            const float dist2 = length_sq(v3(h.x, h.y, h.z) - pos);
+            if (dist2 < d2max) {
+                const float4 c0 = M.cold[2 * (size_t)me];
+                accept = !(dot(v3(c0.x, c0.y, c0.z), normal) >= 0);
+            }
+        }
+        __syncthreads(); // every lane has read its stack slot
+        const uint64_t mn = __ballot(push_near), mf = __ballot(push_far), ma = __ballot(accept);
+        const uint32_t cn = (uint32_t)__popcll(mn);
+        if (top + cn + (uint32_t)__popcll(mf) > BHRT_WAVE_STACK) return 3; // cannot happen for trees below 2^31 nodes (<= 64 * depth entries)
+        if (push_near) L.stack[top + (uint32_t)__popcll(mn & lt)] = nearc;
+        if (push_far) L.stack[top + cn + (uint32_t)__popcll(mf & lt)] = nearc ^ 1u;
+        top += cn + (uint32_t)__popcll(mf);
+        if (ma) {
+            if (n_acc + (uint32_t)__popcll(ma) >= BHRT_PHOTON_K) return 2;
+            if (accept) L.node[n_acc + (uint32_t)__popcll(ma & lt)] = me;
+            n_acc += (uint32_t)__popcll(ma);
+        }
+        __syncthreads();
+    }
+    if (n_acc == 0) return 0;
+    // walk order: rank keys, bitonic sort of the (key, node) pairs in LDS
+    uint32_t n_sort = 64;
+    while (n_sort < n_acc) n_sort <<= 1;
+    for (uint32_t i = lane; i < n_sort; i += 64) L.key[i] = i < n_acc ? photon_walk_rank(M, pos, L.node[i]) : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= n_sort; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < n_sort / 2; t += 64) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j; // pair (i, i + j), ascending where (i & k) == 0
+                const unsigned long long a = L.key[i], b = L.key[p];
+                if ((a > b) == ((i & k) == 0)) {
+                    L.key[i] = b; L.key[p] = a;
+                    const uint32_t na = L.node[i]; L.node[i] = L.node[p]; L.node[p] = na;
+                }
+            }
+            __syncthreads();
+        }
+    // ordered sums, 64 photons staged at a time
+    V3 sumI = v3(0, 0, 0), sumD = v3(0, 0, 0);
+    for (uint32_t base = 0; base < n_acc; base += 64) {
+        const uint32_t m = n_acc - base < 64u ? n_acc - base : 64u;
+        if (lane < m) {
+            const size_t k = L.node[base + lane];
+            const float4 c0 = M.cold[2 * k], c1 = M.cold[2 * k + 1];
+            L.val[0][lane] = c0.x; L.val[1][lane] = c0.y; L.val[2][lane] = c0.z; L.val[3][lane] = c0.w;
+            L.val[4][lane] = c1.x; L.val[5][lane] = c1.y; L.val[6][lane] = c1.z;
+        }
+        __syncthreads();
+        if (lane == 0)
+            for (uint32_t i = 0; i < m; i++) {
+                sumI = sumI + 1.f * v3(L.val[4][i], L.val[5][i], L.val[6][i]);
+                sumD = sumD + v3(L.val[0][i], L.val[1][i], L.val[2][i]) * (1.f * L.val[3][i]);
+            }
+        __syncthreads();
+    }
+    if (lane == 0) photon_finish(sumI, sumD, d2max, irrad, direction);
+    return 1;
+}
+
+// The full replay with the 1000-entry candidate heap (cyPhotonMap.h:439-497,353-365).  cand: this lane's scratch column,
+// element k at [k * stride]; one 8-byte entry = (bits of dist2) << 32 | photon index, so a sift step moves one word
+// (dist2 >= 0: the float order is the order of the bit patterns, but the comparisons below stay float comparisons).
+__device__ inline float cand_d2(unsigned long long e) { return __uint_as_float((uint32_t)(e >> 32)); }
+__device__ inline unsigned long long make_cand(float d2, uint32_t idx) { return ((unsigned long long)__float_as_uint(d2) << 32) | idx; }
+__device__ inline bool photon_estimate_heap(const PhotonMapDev &M, V3 pos, V3 normal, float radius, unsigned long long *cand, size_t stride,
+                                            V3 &irrad, V3 &direction)
+{
+    irrad = v3(0, 0, 0);
+    direction = v3(0, 0, 0);
+    if (M.n <= 0) return false;
+    float d2max = radius * radius; // np.dist2[0]
+    int found = 0;
+    PhotonWalk w;
+    int node;
+    float4 h;
+    while (photon_walk_next(M, w, pos, d2max, node, h)) {
+        const float dist2 = length_sq(v3(h.x, h.y, h.z) - pos);
+        if (!(dist2 < d2max)) continue;
+        const float4 c0 = M.cold[2 * (size_t)node];
+        if (dot(v3(c0.x, c0.y, c0.z), normal) >= 0) continue;
+        if (found < BHRT_PHOTON_K) {
+            found++;
+            cand[(size_t)found * stride] = make_cand(dist2, (uint32_t)node);
+            if (found == BHRT_PHOTON_K) { // build the max-heap
+                const int half_found = found >> 1;
+                for (int k = half_found; k >= 1; k--) {
+                    int parent = k;
+                    const unsigned long long t = cand[(size_t)k * stride];
+                    const float td2 = cand_d2(t);
+                    while (parent <= half_found) {
+                        int j = parent + parent;
+                        unsigned long long cj = cand[(size_t)j * stride];
+                        if (j < found) {
+                            const unsigned long long cj1 = cand[(size_t)(j + 1) * stride];
+                            if (cand_d2(cj) < cand_d2(cj1)) { j++; cj = cj1; }
+                        }
+                        if (td2 >= cand_d2(cj)) break;
+                        cand[(size_t)parent * stride] = cj;
+                        parent = j;
+                    }
+                    cand[(size_t)parent * stride] = t;
+                }
+            }
+        } else {
+            int parent = 1, j = 2;
+            while (j <= found) {
+                unsigned long long cj = cand[(size_t)j * stride];
+                if (j < found) {
+                    const unsigned long long cj1 = cand[(size_t)(j + 1) * stride];
+                    if (cand_d2(cj) < cand_d2(cj1)) { j++; cj = cj1; }
+                }
+                if (dist2 > cand_d2(cj)) break;
+                cand[(size_t)parent * stride] = cj;
+                parent = j;
+                j <<= 1;
+            }
+            cand[(size_t)parent * stride] = make_cand(dist2, (uint32_t)node);
+            d2max = cand_d2(cand[(size_t)1 * stride]);
+        }
+    }
+    if (found == 0) return false;
+    V3 sumI = v3(0, 0, 0), sumD = v3(0, 0, 0); // list order: insertion order below 1000 photons, heap-array order from there on
+    for (int i = 1; i <= found; i++) {
+        const size_t k = (uint32_t)cand[(size_t)i * stride];
+        const float4 c0 = M.cold[2 * k], c1 = M.cold[2 * k + 1];
+        sumI = sumI + 1.f * v3(c1.x, c1.y, c1.z);
+        sumD = sumD + v3(c0.x, c0.y, c0.z) * (1.f * c0.w);
+    }
+    photon_finish(sumI, sumD, d2max, irrad, direction);
     return true;
 }
 #endif // __HIPCC__

@@ -15,6 +15,7 @@
 // No CPU fallback: every entry point fails when there is no usable HIP device.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -718,38 +719,185 @@ __global__ void __launch_bounds__(kBlock) k_photon_scale(DPhoton *photons, uint3
     if (i < n) photons[1 + i].power *= scale;
 }
 // caustic term of frames [f0, f1): brdf * irradiance (MtlBlinn.cpp:329-342) -> F.caustic
-__global__ void __launch_bounds__(kBlock) k_photon_gather_frames(Frames F, uint32_t f0, uint32_t f1, const DPhoton *photons, int n, int half, float radius,
-                                                                  float *scr_d2, uint32_t *scr_idx, size_t stride, const bhrt_material *materials)
+// decode every photon once (hot / cold split, see PhotonMapDev)
+__global__ void __launch_bounds__(kBlock) k_photon_expand(const DPhoton *photons, uint32_t n, float4 *hot, float4 *cold)
 {
-    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t f = f0 + lane;
-    if (f >= f1) return;
-    const uint32_t info = F.info[f];
-    if ((info >> 16) & FF_CONST) return;
-    const V3 p = ld3i(F.ph_p, f), N = ld3i(F.ph_n, f), vV = ld3i(F.ph_v, f);
-    V3 irr, vL;
-    if (!photon_estimate(photons, n, half, p, N, radius, scr_d2 + lane, scr_idx + lane, stride, irr, vL)) {
-        // no photon found: irrad = 0 and vL = (0,0,0) -> cosTheta = -0 is not > 0: no contribution
-        return;
-    }
-    const V3 vN = normalized(N);
-    const float cosTheta = -dot(vL, vN);
-    if (cosTheta > 0) {
-        const V3 vH = normalized(vL + vV);
-        const float gloss = materials[(info >> 20) & 0xfffu].glossiness;
-        const V3 brdf = ld3i(F.ph_kd, f) + ld3i(F.ph_ks, f) * dm::powf_(dot(vH, vN), gloss) / cosTheta;
-        st3(F.caustic, f, brdf * irr);
-    }
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const DPhoton p = photons[i];
+    const V3 d = photon_direction(p), pw = photon_power(p);
+    hot[i] = make_float4(p.pos[0], p.pos[1], p.pos[2], __uint_as_float((uint32_t)(p.planeAndDirZ & 0x3)));
+    cold[2 * (size_t)i] = make_float4(d.x, d.y, d.z, p.power);
+    cold[2 * (size_t)i + 1] = make_float4(pw.x, pw.y, pw.z, 0.f);
 }
-__global__ void __launch_bounds__(kBlock) k_photon_gather_api(const float *p, const float *nrm, uint32_t cnt, const DPhoton *photons, int n, int half, float radius,
-                                                               float *scr_d2, uint32_t *scr_idx, size_t stride, float *irrad, float *dir)
+
+// What a gather kernel does with one finished query.
+struct GatherToFrames { // the caustic term of Shade(), MtlBlinn.cpp:329-342
+    Frames F;
+    const bhrt_material *materials;
+    __device__ bool skip(uint32_t f) const { return ((F.info[f] >> 16) & FF_CONST) != 0; }
+    __device__ V3 pos(uint32_t f) const { return ld3i(F.ph_p, f); }
+    __device__ V3 nrm(uint32_t f) const { return ld3i(F.ph_n, f); }
+    __device__ void done(uint32_t f, bool found, V3 irr, V3 vL) const
+    {
+        if (!found) return; // no photon: irrad = 0 and vL = (0,0,0) -> cosTheta = -0 is not > 0: no contribution (F.caustic stays 0)
+        const V3 vN = normalized(ld3i(F.ph_n, f));
+        const float cosTheta = -dot(vL, vN);
+        if (cosTheta > 0) {
+            const V3 vH = normalized(vL + ld3i(F.ph_v, f));
+            const float gloss = materials[(F.info[f] >> 20) & 0xfffu].glossiness;
+            const V3 brdf = ld3i(F.ph_kd, f) + ld3i(F.ph_ks, f) * dm::powf_(dot(vH, vN), gloss) / cosTheta;
+            st3(F.caustic, f, brdf * irr);
+        }
+    }
+};
+struct GatherToArrays { // bhrt_photon_gather_host
+    const float *p, *n;
+    float *irrad, *dir;
+    __device__ bool skip(uint32_t) const { return false; }
+    __device__ V3 pos(uint32_t i) const { return ld3i(p, i); }
+    __device__ V3 nrm(uint32_t i) const { return ld3i(n, i); }
+    __device__ void done(uint32_t i, bool, V3 irr, V3 d) const { st3(irrad, i, irr); st3(dir, i, d); }
+};
+
+// Gather order.  A wave whose 64 queries lie in one small cell walks the same tree path and touches the same photons
+// (coalesced loads, no divergence), so the queries are counting-sorted by grid cell first: 128^3 cells over the photons'
+// bounds (+ radius), cells numbered along a Morton curve so that neighbouring waves share cache lines too.  The order
+// inside a cell is whatever the atomics give: every query's result is independent of the order.
+#define BHRT_GATHER_CELL_BITS 7
+#define BHRT_GATHER_CELLS (1u << (3 * BHRT_GATHER_CELL_BITS))
+struct GatherGrid { float lo[3], inv_cell[3]; };
+__device__ inline uint32_t spread3(uint32_t v) // 7 bits -> every third bit
+{
+    v &= 0x7fu;
+    v = (v | (v << 8)) & 0x0000700fu;
+    v = (v | (v << 4)) & 0x000430c3u;
+    v = (v | (v << 2)) & 0x00049249u;
+    return v;
+}
+__device__ inline uint32_t gather_cell(const GatherGrid &G, V3 p)
+{
+    const float m = (float)((1 << BHRT_GATHER_CELL_BITS) - 1);
+    const float fx = fminf(fmaxf((p.x - G.lo[0]) * G.inv_cell[0], 0.f), m), fy = fminf(fmaxf((p.y - G.lo[1]) * G.inv_cell[1], 0.f), m),
+                fz = fminf(fmaxf((p.z - G.lo[2]) * G.inv_cell[2], 0.f), m); // NaN -> 0 (fmaxf returns the number)
+    return spread3((uint32_t)fx) | (spread3((uint32_t)fy) << 1) | (spread3((uint32_t)fz) << 2);
+}
+template <class Sink>
+__global__ void __launch_bounds__(kBlock) k_gather_cell_count(Sink sink, uint32_t q0, uint32_t cnt, GatherGrid G, uint32_t *cell_of, uint32_t *cell_count)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cnt) return;
+    const uint32_t c = gather_cell(G, sink.pos(q0 + i));
+    cell_of[i] = c;
+    atomicAdd(&cell_count[c], 1u);
+}
+// exclusive scan of cell_count[BHRT_GATHER_CELLS] in place, three launches: per-block sums, scan of the sums, add back
+constexpr uint32_t kScanBlock = 1024, kScanPerThread = 8, kScanTile = kScanBlock * kScanPerThread;
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *lds /* kScanBlock/64 + 1 */, uint32_t &total)
+{
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if ((int)lane >= off) incl += t; }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t w = 0; w < kScanBlock / 64; w++) { const uint32_t t = lds[w]; lds[w] = run; run += t; } lds[kScanBlock / 64] = run; }
+    __syncthreads();
+    const uint32_t r = lds[wave] + incl - v;
+    total = lds[kScanBlock / 64];
+    __syncthreads();
+    return r;
+}
+__global__ void __launch_bounds__(kScanBlock) k_scan_tiles(uint32_t *data, uint32_t n, uint32_t *tile_sums)
+{
+    __shared__ uint32_t lds[kScanBlock / 64 + 1];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
+    uint32_t v[kScanPerThread], sum = 0;
+    for (uint32_t k = 0; k < kScanPerThread; k++) { v[k] = base + k < n ? data[base + k] : 0u; sum += v[k]; }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(sum, lds, total);
+    for (uint32_t k = 0; k < kScanPerThread; k++) { if (base + k < n) data[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(kScanBlock) k_scan_sums(uint32_t *tile_sums, uint32_t n_tiles) // n_tiles <= kScanBlock
+{
+    __shared__ uint32_t lds[kScanBlock / 64 + 1];
+    const uint32_t v = threadIdx.x < n_tiles ? tile_sums[threadIdx.x] : 0u;
+    uint32_t total;
+    const uint32_t r = block_exclusive_scan(v, lds, total);
+    if (threadIdx.x < n_tiles) tile_sums[threadIdx.x] = r;
+}
+__global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t *data, uint32_t n, const uint32_t *tile_sums)
+{
+    const uint32_t add = tile_sums[blockIdx.x];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
+    for (uint32_t k = 0; k < kScanPerThread; k++) if (base + k < n) data[base + k] += add;
+}
+__global__ void __launch_bounds__(kBlock) k_gather_cell_scatter(uint32_t q0, uint32_t cnt, const uint32_t *cell_of, uint32_t *cell_cursor, uint32_t *order)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    order[atomicAdd(&cell_cursor[cell_of[i]], 1u)] = q0 + i;
+}
+
+// Pass 1: every query walks the map without a candidate list (photon_estimate_fast).  Queries that meet their 1000th
+// photon are appended to `heavy` (pass 3), queries whose walk is longer than the lane budget to `longq` (pass 2).
+// order: optional permutation of the queries (cell-sorted, see above).
+#define BHRT_GATHER_LANE_BUDGET 4096
+__device__ inline void wave_append(bool flag, uint32_t value, uint32_t *list, uint32_t *count)
+{
+    const uint64_t m = __ballot(flag);
+    if (!m) return;
+    uint32_t base = 0;
+    if (__lane_id() == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (flag) list[base + (uint32_t)__popcll(m & ((1ull << __lane_id()) - 1ull))] = value;
+}
+template <class Sink>
+__global__ void __launch_bounds__(kBlock) k_photon_gather_fast(Sink sink, uint32_t q0, uint32_t cnt, const uint32_t *order, PhotonMapDev M, float radius,
+                                                               int lane_budget, uint32_t *heavy, uint32_t *longq, uint32_t *counts /* [0] heavy, [1] long */)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = 0;
+    uint32_t q = 0;
+    if (i < cnt) {
+        q = order ? order[i] : q0 + i;
+        if (!sink.skip(q)) {
+            V3 irr, d;
+            r = photon_estimate_fast(M, sink.pos(q), sink.nrm(q), radius, lane_budget, irr, d);
+            if (r < 2) sink.done(q, r == 1, irr, d);
+        }
+    }
+    wave_append(r == 2, q, heavy, &counts[0]);
+    wave_append(r == 3, q, longq, &counts[1]);
+}
+// Pass 2: the long walks, one wave per query (photon_estimate_wave); blocks stride over the list until it is exhausted.
+template <class Sink>
+__global__ void __launch_bounds__(64) k_photon_gather_wave(Sink sink, const uint32_t *longq, PhotonMapDev M, float radius, uint32_t *heavy, uint32_t *counts)
+{
+    __shared__ WaveGatherLds lds;
+    const uint32_t n_long = counts[1];
+    for (uint32_t i = blockIdx.x; i < n_long; i += gridDim.x) {
+        const uint32_t q = longq[i];
+        V3 irr, d;
+        const int r = photon_estimate_wave(M, lds, sink.pos(q), sink.nrm(q), radius, irr, d);
+        if (threadIdx.x == 0) {
+            if (r >= 2) heavy[atomicAdd(&counts[0], 1u)] = q;
+            else sink.done(q, r == 1, irr, d);
+        }
+        __syncthreads();
+    }
+}
+// Pass 3: the queries of heavy[h0, h0+cnt) with the full candidate heap, one scratch column per lane.
+template <class Sink>
+__global__ void __launch_bounds__(kBlock) k_photon_gather_heap(Sink sink, const uint32_t *heavy, uint32_t h0, uint32_t cnt, PhotonMapDev M, float radius,
+                                                               unsigned long long *scr, size_t stride)
+{
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= cnt) return;
+    const uint32_t q = heavy[h0 + lane];
     V3 irr, d;
-    photon_estimate(photons, n, half, ld3i(p, i), ld3i(nrm, i), radius, scr_d2 + i, scr_idx + i, stride, irr, d);
-    st3(irrad, i, irr);
-    st3(dir, i, d);
+    const bool found = photon_estimate_heap(M, sink.pos(q), sink.nrm(q), radius, scr + lane, stride, irr, d);
+    sink.done(q, found, irr, d);
 }
 
 // ================================================================================================
@@ -789,9 +937,16 @@ struct DeviceState {
     std::vector<HostPhoton> h_photons; // balanced copy for bhrt_photon_export
     float *d_ph_frames = nullptr;      // 15 * cap_frames floats (p, N, V, kd, ks per frame), only with photon_map
     uint32_t ph_frames_cap = 0;
-    float *d_scr_d2 = nullptr;
-    uint32_t *d_scr_idx = nullptr;
+    float4 *d_ph_hot = nullptr, *d_ph_cold = nullptr; // decoded copy the gather walks (PhotonMapDev)
+    PhotonMapDev pm;
+    unsigned long long *d_scr = nullptr; // candidate heaps of the heavy queries: (K+1) x scr_lanes, element-major
     uint32_t scr_lanes = 0;
+    uint32_t *d_heavy = nullptr; // queries that met 1000 photons in pass 1
+    uint32_t heavy_cap = 0;
+    uint32_t *d_n_heavy = nullptr, *h_n_heavy = nullptr; // [0] heavy, [1] long
+    uint32_t *d_long = nullptr;  // queries whose walk outlasted the lane budget in pass 1
+    uint32_t *d_cell_of = nullptr, *d_gorder = nullptr; // gather order (cell sort): heavy_cap entries each
+    uint32_t *d_cells = nullptr, *d_tile_sums = nullptr;
     // scratch for the public trace API
     float *d_api_f = nullptr;
     int32_t *d_api_i = nullptr;
@@ -806,7 +961,8 @@ void DestroyDeviceState(DeviceState *d)
     fr(d->d_blob); fr(d->d_chain);
     for (int k = 0; k < 2; k++) { fr(d->d_rayf[k]); fr(d->d_rayu[k]); }
     fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_seg); fr(d->d_cnt);
-    fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr_d2); fr(d->d_scr_idx);
+    fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_cells); fr(d->d_tile_sums);
+    if (d->h_n_heavy) (void)hipHostFree(d->h_n_heavy);
     if (d->h_cnt) (void)hipHostFree(d->h_cnt);
     for (int k = 0; k < 2; k++) if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
     for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
@@ -921,7 +1077,7 @@ static void FlushTimers(DeviceState *D) // call after the stream has been synchr
 {
     for (auto &p : D->ev_pending) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, D->ev_pool[p.e0], D->ev_pool[p.e1]) == hipSuccess) *p.acc += ms * 1e-3;
+        if (p.acc && hipEventElapsedTime(&ms, D->ev_pool[p.e0], D->ev_pool[p.e1]) == hipSuccess) *p.acc += ms * 1e-3;
     }
     D->ev_pending.clear();
     D->ev_used = 0;
@@ -930,12 +1086,76 @@ static void FlushTimers(DeviceState *D) // call after the stream has been synchr
 static int EnsurePhotonScratch(DeviceState *D, uint32_t lanes)
 {
     if (D->scr_lanes >= lanes) return BHRT_OK;
-    if (D->d_scr_d2) (void)hipFree(D->d_scr_d2);
-    if (D->d_scr_idx) (void)hipFree(D->d_scr_idx);
-    D->d_scr_d2 = nullptr; D->d_scr_idx = nullptr; D->scr_lanes = 0;
-    HIP_CHECK(hipMalloc(&D->d_scr_d2, (size_t)lanes * (BHRT_PHOTON_K + 1) * sizeof(float)));
-    HIP_CHECK(hipMalloc(&D->d_scr_idx, (size_t)lanes * (BHRT_PHOTON_K + 1) * sizeof(uint32_t)));
+    if (D->d_scr) (void)hipFree(D->d_scr);
+    D->d_scr = nullptr; D->scr_lanes = 0;
+    HIP_CHECK(hipMalloc(&D->d_scr, (size_t)lanes * (BHRT_PHOTON_K + 1) * sizeof(unsigned long long)));
     D->scr_lanes = lanes;
+    return BHRT_OK;
+}
+
+// Caustic gather of queries [q0, q0+cnt) of `sink`: pass 1 without candidate lists over all of them, pass 2 with the
+// candidate heap for the few that met 1000 photons (in chunks of the scratch columns).
+template <class Sink>
+static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt, float radius, bhrt_stats *st)
+{
+    if (cnt == 0) return BHRT_OK;
+    if (D->heavy_cap < cnt) {
+        auto fr = [](uint32_t *&p) { if (p) (void)hipFree(p); p = nullptr; };
+        fr(D->d_heavy); fr(D->d_long); fr(D->d_cell_of); fr(D->d_gorder);
+        D->heavy_cap = 0;
+        HIP_CHECK(hipMalloc(&D->d_heavy, (size_t)cnt * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&D->d_long, (size_t)cnt * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&D->d_cell_of, (size_t)cnt * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&D->d_gorder, (size_t)cnt * sizeof(uint32_t)));
+        D->heavy_cap = cnt;
+    }
+    if (!D->d_n_heavy) {
+        HIP_CHECK(hipMalloc(&D->d_n_heavy, 2 * sizeof(uint32_t)));
+        HIP_CHECK(hipHostMalloc(&D->h_n_heavy, 2 * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&D->d_cells, (size_t)BHRT_GATHER_CELLS * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&D->d_tile_sums, (size_t)kScanBlock * sizeof(uint32_t)));
+    }
+    static_assert(BHRT_GATHER_CELLS / kScanTile <= kScanBlock, "one block scans the tile sums");
+    const dim3 grid((cnt + kBlock - 1) / kBlock), block(kBlock);
+    const uint32_t *order = nullptr;
+    if (cnt >= (1u << 16)) { // small batches are latency-bound anyway
+        GatherGrid G;
+        for (int k = 0; k < 3; k++) {
+            const float lo = D->pm.lo[k] - radius, hi = D->pm.hi[k] + radius;
+            G.lo[k] = lo;
+            G.inv_cell[k] = hi > lo ? (float)(1 << BHRT_GATHER_CELL_BITS) / (hi - lo) : 0.f;
+        }
+        const uint32_t n_tiles = BHRT_GATHER_CELLS / kScanTile;
+        HIP_CHECK(hipMemsetAsync(D->d_cells, 0, (size_t)BHRT_GATHER_CELLS * sizeof(uint32_t), D->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_cell_count<Sink>), grid, block, 0, D->stream, sink, q0, cnt, G, D->d_cell_of, D->d_cells);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, D->d_cells, BHRT_GATHER_CELLS, D->d_tile_sums);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, D->stream, D->d_tile_sums, n_tiles);
+        hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, D->d_cells, BHRT_GATHER_CELLS, D->d_tile_sums);
+        hipLaunchKernelGGL(k_gather_cell_scatter, grid, block, 0, D->stream, q0, cnt, D->d_cell_of, D->d_cells, D->d_gorder);
+        order = D->d_gorder;
+    }
+    HIP_CHECK(hipMemsetAsync(D->d_n_heavy, 0, 2 * sizeof(uint32_t), D->stream));
+    int lane_budget = BHRT_GATHER_LANE_BUDGET;
+    if (const char *e = getenv("BHRT_GATHER_LANE_BUDGET")) lane_budget = std::max(1, atoi(e)); // test knob: a tiny budget sends every query through pass 2
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_fast<Sink>), grid, block, 0, D->stream, sink, q0, cnt, order, D->pm, radius, lane_budget, D->d_heavy,
+                       D->d_long, D->d_n_heavy);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_wave<Sink>), dim3(std::min<uint32_t>(cnt, 2048u)), dim3(64), 0, D->stream, sink, D->d_long, D->pm, radius,
+                       D->d_heavy, D->d_n_heavy);
+    HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_n_heavy, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
+    HIP_CHECK(hipStreamSynchronize(D->stream));
+    const uint32_t n_heavy = D->h_n_heavy[0];
+    if (st) st->reserved[3] += (double)D->h_n_heavy[1];
+    if (n_heavy == 0) return BHRT_OK;
+    int rc = EnsurePhotonScratch(D, std::min<uint32_t>(1u << 20, (n_heavy + 4095u) & ~4095u));
+    if (rc) return rc;
+    Timer t(D, st ? &st->reserved[1] : nullptr);
+    for (uint32_t h0 = 0; h0 < n_heavy; h0 += D->scr_lanes) {
+        const uint32_t m = std::min<uint32_t>(D->scr_lanes, n_heavy - h0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_heap<Sink>), dim3((m + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, sink, D->d_heavy, h0, m,
+                           D->pm, radius, D->d_scr, (size_t)D->scr_lanes);
+    }
+    t.Stop();
+    if (st) st->reserved[2] += (double)n_heavy;
     return BHRT_OK;
 }
 
@@ -984,8 +1204,6 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 HIP_CHECK(hipMalloc(&D->d_ph_frames, (size_t)D->cap_frames * 15 * sizeof(float)));
                 D->ph_frames_cap = D->cap_frames;
             }
-            rc = EnsurePhotonScratch(D, 1u << 20);
-            if (rc) return rc;
         }
         if (pass_limit == 0) pass_limit = pass_samples;
         if (pass_limit > D->cap_samples) pass_limit = D->cap_samples;
@@ -1043,11 +1261,9 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             }
             if (o.photon_map && D->h_cnt->n_frames.v > frame_marks.back()) { // caustic term of the frames opened in this step
                 Timer t(D, &st->reserved[0]);
-                for (uint32_t fb = frame_marks.back(); fb < D->h_cnt->n_frames.v; fb += D->scr_lanes) {
-                    const uint32_t fe = std::min<uint32_t>(D->h_cnt->n_frames.v, fb + D->scr_lanes);
-                    hipLaunchKernelGGL(k_photon_gather_frames, dim3((fe - fb + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, F, fb, fe, D->d_photons, (int)D->n_photons,
-                                       (int)D->n_photons / 2 - 1, 0.5f /* MAX_Area, MtlBlinn.cpp:29 */, D->d_scr_d2, D->d_scr_idx, (size_t)D->scr_lanes, D->S.materials);
-                }
+                const GatherToFrames sink = {F, D->S.materials};
+                rc = RunGather(D, sink, frame_marks.back(), D->h_cnt->n_frames.v - frame_marks.back(), 0.5f /* MAX_Area, MtlBlinn.cpp:29 */, st);
+                if (rc) return rc;
                 t.Stop();
             }
             frame_marks.push_back(D->h_cnt->n_frames.v);
@@ -1383,6 +1599,21 @@ int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_pho
     HIP_CHECK(hipMemcpy(d_out, D->h_photons.data(), ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyHostToDevice));
     D->d_photons = d_out;
     D->n_photons = n;
+    // decoded copy for the gather (PhotonMapDev) + the bounds of the photon positions
+    if (D->d_ph_hot) (void)hipFree(D->d_ph_hot);
+    if (D->d_ph_cold) (void)hipFree(D->d_ph_cold);
+    D->d_ph_hot = nullptr; D->d_ph_cold = nullptr;
+    HIP_CHECK(hipMalloc(&D->d_ph_hot, ((size_t)n + 1) * sizeof(float4)));
+    HIP_CHECK(hipMalloc(&D->d_ph_cold, ((size_t)n + 1) * 2 * sizeof(float4)));
+    hipLaunchKernelGGL(k_photon_expand, dim3((n + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, d_out, n, D->d_ph_hot, D->d_ph_cold);
+    HIP_CHECK(hipStreamSynchronize(D->stream));
+    D->pm.hot = D->d_ph_hot; D->pm.cold = D->d_ph_cold; D->pm.n = (int)n; D->pm.half = (int)n / 2 - 1;
+    for (int k = 0; k < 3; k++) { D->pm.lo[k] = BHRT_BIGFLOAT; D->pm.hi[k] = -BHRT_BIGFLOAT; }
+    for (size_t i = 1; i <= n; i++)
+        for (int k = 0; k < 3; k++) {
+            D->pm.lo[k] = std::min(D->pm.lo[k], D->h_photons[i].pos[k]);
+            D->pm.hi[k] = std::max(D->pm.hi[k], D->h_photons[i].pos[k]);
+        }
     if (n_stored) *n_stored = n;
     return BHRT_OK;
 }
@@ -1395,17 +1626,16 @@ int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *nrm,
     if (!D->d_photons) { SetError("photon map: call bhrt_photon_build first"); return BHRT_ERR_ARG; }
     if (!p || !nrm || !irrad || !dir) { SetError("null buffer"); return BHRT_ERR_ARG; }
     if (cnt == 0) return BHRT_OK;
-    const uint32_t chunk = 1u << 18;
-    rc = EnsurePhotonScratch(D, chunk);
-    if (rc) return rc;
+    const uint32_t chunk = 1u << 20;
     float *d_buf = nullptr;
     HIP_CHECK(hipMalloc(&d_buf, (size_t)chunk * 12 * sizeof(float)));
     for (size_t b = 0; b < cnt; b += chunk) {
         const uint32_t m = (uint32_t)std::min<size_t>(chunk, cnt - b);
         HIP_CHECK(hipMemcpy(d_buf, p + b * 3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d_buf + (size_t)chunk * 3, nrm + b * 3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_photon_gather_api, dim3((m + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, d_buf, d_buf + (size_t)chunk * 3, m, D->d_photons, (int)D->n_photons,
-                           (int)D->n_photons / 2 - 1, radius, D->d_scr_d2, D->d_scr_idx, (size_t)D->scr_lanes, d_buf + (size_t)chunk * 6, d_buf + (size_t)chunk * 9);
+        const GatherToArrays sink = {d_buf, d_buf + (size_t)chunk * 3, d_buf + (size_t)chunk * 6, d_buf + (size_t)chunk * 9};
+        rc = RunGather(D, sink, 0, m, radius, nullptr);
+        if (rc) { (void)hipFree(d_buf); return rc; }
         HIP_CHECK(hipStreamSynchronize(D->stream));
         HIP_CHECK(hipMemcpy(irrad + b * 3, d_buf + (size_t)chunk * 6, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost));
         HIP_CHECK(hipMemcpy(dir + b * 3, d_buf + (size_t)chunk * 9, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost));

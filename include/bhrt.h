@@ -78,7 +78,7 @@ typedef struct bhrt_stats {
     double seconds_total;    /* wall clock of the call, scene already resident */
     double seconds_trace_closest, seconds_trace_shadow, seconds_shade, seconds_other; /* HIP-event kernel time */
     uint64_t launches_trace_closest, launches_trace_shadow;
-    double reserved[4]; /* [0] = seconds in the photon gather kernel */
+    double reserved[4]; /* [0] = seconds in the photon gather (all of it), [1] = of which in the candidate-heap pass, [2] = queries that needed it, [3] = queries walked by a whole wave */
 } bhrt_stats;
 
 /* compact hit record written by the trace kernel (SoA on the device: one array per field) */

@@ -94,6 +94,21 @@ def test_gpu_photon_map_vs_oracle(B, load_scene, O):
         oi, od = O.photon_gather(p, nr, radius)
         assert same_bits(gi, oi) and same_bits(gd, od)
     assert (oi.sum(1) > 0).sum() > 300
+    # the three gather passes agree: lane walk only / every query by a whole wave (walk order rebuilt by rank sort) / default mix
+    import os
+    rn = rng.normal(size=(len(p), 3)).astype(np.float32)
+    rn /= np.linalg.norm(rn, axis=1, keepdims=True)
+    for radius in (0.5, 1.1):
+        oi, od = O.photon_gather(p, rn, radius)
+        for budget in ("1000000000", "1", None):
+            if budget is None:
+                os.environ.pop("BHRT_GATHER_LANE_BUDGET", None)
+            else:
+                os.environ["BHRT_GATHER_LANE_BUDGET"] = budget
+            gi, gd = sc.photon_gather(p, rn, radius)
+            assert same_bits(gi, oi) and same_bits(gd, od), (radius, budget)
+    found = (oi.sum(1) > 0)
+    assert found.sum() > 100 and (~found).sum() > 100
     # radiance with the caustic term
     region = (90, 150, 200, 215)
     ropts = B.default_opts(spp=2, gi_bounces=2, seed=3, photon_map=1)
