@@ -200,22 +200,37 @@ __device__ inline uint32_t node_data(const MeshRef &M, uint32_t i) { return i < 
 //     from the SECOND-visited child: return (first child's r) ? true : r
 //   children are adjacent and the first child's id is even (cyBVH.h:281-291), so sibling = id ^ 1.
 // Trail: bit (depth-1) of inFar / nearHit per level; depth <= 64 is checked at upload.
-__device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront)
-{
-    float tm;
-    const RayRcp rr = ray_rcp(d);
-    const NodeRec root = node_at(M, 1);
-    if (!box_hit_rcp(root.b, o, d, rr, ht, tm)) return false;
-    const float dlen = length(d);
-    uint32_t cur = 1;
-    int depth = 0;
-    uint64_t inFar = 0, nearHit = 0;
-    bool desc = true, r = false, any = false;
-    uint32_t data = root.data;
-    // "while-while" form of the state machine: the lanes of a wave run the three phases together (descend through
-    // inner nodes / test a leaf / climb), so a wave executes max-per-phase work instead of the union of all
-    // three bodies on every step.
-    while (true) {
+// The traversal is an object (begin / round) so that a kernel can interleave it with other work; mesh_closest() below
+// is the plain "run to the end" form.
+struct MeshTrav {
+    V3 o, d;
+    RayRcp rr;
+    float dlen;
+    int side;
+    uint32_t cur, data;
+    int depth;
+    uint64_t inFar, nearHit;
+    bool desc, r, any, alive;
+    float ht;
+    int hprim, hfront;
+
+    // root box gate of TriObj::IntersectRay; ht/hprim/hfront = the hit so far
+    __device__ void begin(const MeshRef &M, V3 o_, V3 d_, int side_, float ht_, int hprim_, int hfront_)
+    {
+        o = o_; d = d_; side = side_; ht = ht_; hprim = hprim_; hfront = hfront_;
+        rr = ray_rcp(d);
+        any = false; r = false; desc = true; cur = 1; depth = 0; inFar = 0; nearHit = 0;
+        float tm;
+        const NodeRec root = node_at(M, 1);
+        data = root.data;
+        alive = box_hit_rcp(root.b, o, d, rr, ht, tm);
+        dlen = length(d);
+    }
+    // One round of the "while-while" form of the state machine: the lanes of a wave run the three phases together
+    // (descend through inner nodes / test a leaf / climb), so a wave executes max-per-phase work instead of the union
+    // of all three bodies on every step.  Call only while alive.
+    __device__ void round(const MeshRef &M)
+    {
         // ---- phase 1: descend through inner nodes
         while (desc && !(data & 0x80000000u)) {
             const uint32_t c1 = data & 0x7fffffffu;
@@ -272,9 +287,16 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
                 depth--;
             }
         }
-        if (!desc) break; // depth == 0: the root call returned
+        if (!desc) alive = false; // depth == 0: the root call returned
     }
-    return any;
+};
+__device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront)
+{
+    MeshTrav T;
+    T.begin(M, o, d, side, ht, hprim, hfront);
+    while (T.alive) T.round(M);
+    ht = T.ht; hprim = T.hprim; hfront = T.hfront;
+    return T.any;
 }
 
 // TriObj::ShadowRecursive + TraceBVHShadow (TriObj.cpp:41-66,272-307): pre-order walk (child1 then child2 — the
@@ -384,10 +406,24 @@ __device__ inline void stage_nodelet(const DevScene &S, int mesh, bhrt_bvh_node 
     M.n_lds = cnt;
 }
 
+// recursive() (Main.cpp:389-413) over the flattened scene graph.
 // lds == nullptr: no staging (any thread may call it alone); otherwise ALL threads of the block must call it together.
-__device__ inline void trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit &h, bool active = true, bhrt_bvh_node *lds = nullptr)
+// start > 0: resume at scene node `start` with the hit so far in h (k_trace_mesh).  park = true: stop at the first mesh
+// whose root box the ray hits and return that node's index (the caller parks the ray there); -1 = ran to the end.
+// park_key (park only): coherence key of the parked ray = Morton cell of its entry point into the mesh's box + direction octant.
+__device__ inline uint32_t park_spread(uint32_t v) // 5 bits -> every third bit
 {
-    h.t = BHRT_BIGFLOAT; h.node = -1; h.prim = -1; h.front = 1;
+    v &= 0x1fu;
+    v = (v | (v << 8)) & 0x0000100fu;
+    v = (v | (v << 4)) & 0x000010c3u;
+    v = (v | (v << 2)) & 0x00001249u;
+    return v;
+}
+__device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit &h, bool active = true, bhrt_bvh_node *lds = nullptr, int start = 0,
+                                    bool park = false, uint32_t *park_key = nullptr)
+{
+    if (start == 0) { h.t = BHRT_BIGFLOAT; h.node = -1; h.prim = -1; h.front = 1; }
+    int parked = -1;
     for (int n = 0; n < S.n_nodes; n++) {
         const int type = S.nodes[n].obj_type;
         if (type == BHRT_OBJ_NONE) continue;
@@ -396,7 +432,7 @@ __device__ inline void trace_closest(const DevScene &S, V3 o, V3 d, int side, Hi
             if (lds) stage_nodelet(S, S.nodes[n].mesh, lds, M);
             else M = mesh_ref(S, S.nodes[n].mesh);
         }
-        if (!active) continue;
+        if (!active || n < start || parked >= 0) continue;
         V3 lp = o, ld = d;
         local_ray(S, n, lp, ld);
         float t;
@@ -405,10 +441,26 @@ __device__ inline void trace_closest(const DevScene &S, V3 o, V3 d, int side, Hi
             if (sphere_hit(lp, ld, side, h.t, t, fr)) { h.t = t; h.node = n; h.prim = -1; h.front = fr; }
         } else if (type == BHRT_OBJ_PLANE) {
             if (plane_hit(lp, ld, side, h.t, t, fr)) { h.t = t; h.node = n; h.prim = -1; h.front = fr; }
+        } else if (park) {
+            float tm; // the root box gate of TriObj::IntersectRay (TriObj.cpp:17-39), repeated by mesh_closest on resume
+            const NodeRec root = node_at(M, 1);
+            if (box_hit_rcp(root.b, lp, ld, ray_rcp(ld), h.t, tm)) {
+                parked = n;
+                if (park_key) { // ordering hint only: any value is correct
+                    const V3 e = tm > 0 ? lp + tm * ld : lp;
+                    const float m = 31.f;
+                    const float cx = fminf(fmaxf((e.x - root.b[0]) / (root.b[3] - root.b[0]) * 32.f, 0.f), m);
+                    const float cy = fminf(fmaxf((e.y - root.b[1]) / (root.b[4] - root.b[1]) * 32.f, 0.f), m);
+                    const float cz = fminf(fmaxf((e.z - root.b[2]) / (root.b[5] - root.b[2]) * 32.f, 0.f), m);
+                    const uint32_t oct = (ld.x < 0 ? 1u : 0u) | (ld.y < 0 ? 2u : 0u) | (ld.z < 0 ? 4u : 0u);
+                    *park_key = (oct << 15) | park_spread((uint32_t)cx) | (park_spread((uint32_t)cy) << 1) | (park_spread((uint32_t)cz) << 2);
+                }
+            }
         } else {
             if (mesh_closest(M, lp, ld, side, h.t, h.prim, h.front)) h.node = n;
         }
     }
+    return parked;
 }
 
 // GenLight::Shadow (GenLight.cpp:10-69).  The result is an OR over per-node tests that do not influence each

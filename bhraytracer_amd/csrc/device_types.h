@@ -85,7 +85,7 @@ struct Counters {
     Line n_frames;  // frames allocated so far in this pass
     Line overflow;  // set when a capacity was exceeded
     // traced rays sorted for shading: class x shard element counts (see RayOrder)
-    Line cls[3][BHRT_ORDER_SHARDS];
+    Line cls[4][BHRT_ORDER_SHARDS];
 };
 #define BHRT_COUNTERS_HOST_BYTES (4 * 128)
 
@@ -98,15 +98,29 @@ struct Counters {
 // One atomic per wave and class, on counters sharded BHRT_ORDER_SHARDS ways by wave index, each on its own
 // 128-byte line (one line takes only ~88 atomics/us; a workgroup-level barrier here would hold the whole
 // workgroup until its slowest ray is done).
-enum : uint32_t { RC_HEAVY = 0, RC_MEDIUM = 1, RC_LIGHT = 2, RC_NONE = 3 };
+//
+// A fourth list, filled by the first trace kernel of a step when the scene has meshes: rays that reached a mesh whose
+// root box they hit.  They are parked there (hit so far + the scene node to resume at, in the hit buffer) and finished
+// by k_trace_mesh in dense waves — in the mixed launch a wave pays a full BVH traversal for every few mesh rays it holds.
+//   3 mesh    parked at a mesh node (not a shading class: k_trace_mesh files the finished ray under 0..2)
+enum : uint32_t { RC_HEAVY = 0, RC_MEDIUM = 1, RC_LIGHT = 2, RC_MESH = 3, RC_NONE = 4 };
 struct RayOrder {
-    uint32_t *idx;      // [3][BHRT_ORDER_SHARDS][shard_cap] ray indices
+    uint32_t *idx;      // [4][BHRT_ORDER_SHARDS][shard_cap] ray indices
     uint32_t shard_cap;
     // written by k_order_prefix after the trace kernel: first k_shade workgroup of every (class, shard) segment
     // (+ one end marker) and the segment's element count, both compact so that a workgroup finds its segment
     // with two loads per lane instead of walking 96 counter lines
     uint32_t *seg_start; // [3 * BHRT_ORDER_SHARDS + 1]
     uint32_t *seg_count; // [3 * BHRT_ORDER_SHARDS]
+    // the same for the parked mesh rays (k_mesh_prefix): first k_trace_mesh workgroup / element count per shard
+    uint32_t *mesh_start; // [BHRT_ORDER_SHARDS + 1]
+    uint32_t *mesh_count; // [BHRT_ORDER_SHARDS + 1]: per shard, then the total
+    // coherence sort of the parked rays (counting sort by BHRT_PARK_KEY_BITS-bit key: entry cell in the mesh's box + direction octant)
+    uint32_t *park_key;   // [cap_rays] key of ray i, written when it is parked
+    uint32_t *park_sorted; // [cap_rays] the parked ray indices in key order
+    uint32_t *park_bucket; // [1 << BHRT_PARK_KEY_BITS] + tile sums behind it
 };
+#define BHRT_PARK_CELL_BITS 5
+#define BHRT_PARK_KEY_BITS (3 * BHRT_PARK_CELL_BITS + 3)
 
 } // namespace bhrt

@@ -161,10 +161,51 @@ __global__ void __launch_bounds__(kBlock) k_camera_rays(DevScene S, PassInfo P, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// meta == nullptr: every ray uses `uniform_side` (public bhrt_trace_closest_*)
+// Files ray i under a list of the shading order (device_types.h::RayOrder): one atomic per wave and list.
+// ALL lanes of the wave must call it (cls = RC_NONE for lanes without a ray).
+__device__ inline void file_ray(uint32_t cls, uint32_t i, uint32_t shard /* wave-uniform */, const RayOrder &ord, Counters *cnt)
+{
+    const uint32_t lane = __lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint64_t m0 = __ballot(cls == RC_HEAVY), m1 = __ballot(cls == RC_MEDIUM), m2 = __ballot(cls == RC_LIGHT), m3 = __ballot(cls == RC_MESH);
+    uint32_t base = 0;
+    if (lane < 4) { // lanes 0..3 reserve room for lists 0..3
+        const uint64_t mk = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+        const uint32_t c = (uint32_t)__popcll(mk);
+        if (c) base = atomicAdd(&cnt->cls[lane][shard].v, c);
+    }
+    // broadcast the bases with ALL lanes executing the shuffles (a lane-0..3 ray may itself be listless)
+    const uint32_t wshard = shard;
+    const uint32_t b0 = __shfl(base, 0), b1 = __shfl(base, 1), b2 = __shfl(base, 2), b3 = __shfl(base, 3);
+    if (cls != RC_NONE) {
+        const uint64_t mm = cls == RC_HEAVY ? m0 : (cls == RC_MEDIUM ? m1 : (cls == RC_LIGHT ? m2 : m3));
+        const uint32_t pos = (cls == RC_HEAVY ? b0 : (cls == RC_MEDIUM ? b1 : (cls == RC_LIGHT ? b2 : b3))) + (uint32_t)__popcll(mm & lt);
+        if (pos < ord.shard_cap) ord.idx[((size_t)cls * BHRT_ORDER_SHARDS + wshard) * ord.shard_cap + pos] = i;
+        else atomicOr(&cnt->overflow.v, 8u);
+    }
+}
+// shading class of a finished ray; same predicate as k_shade's `new_frame`
+__device__ inline uint32_t shading_class(uint32_t meta, const Hit &hit)
+{
+    const uint32_t kind = meta & 15u;
+    const bool is_hit = hit.node >= 0;
+    bool heavy = false;
+    if (is_hit) {
+        if (kind == RK_CAMERA) heavy = true;
+        else if (kind == RK_GI) heavy = fabsf(hit.t) > BHRT_BIAS;
+        else if (kind == RK_REFR_IN) heavy = hit.front != 0;
+        else heavy = true;
+    }
+    return heavy ? RC_HEAVY : ((kind == RK_REFR_IN && is_hit) ? RC_MEDIUM : RC_LIGHT);
+}
+
+// Closest hit of every queued ray.  meta == nullptr: every ray uses `uniform_side` (public bhrt_trace_closest_*).
+// kPark (scenes with meshes, render path): rays that reach a mesh whose root box they hit are parked on list RC_MESH
+// with their state in the hit buffer (front = front | (node + 1) << 8) and finished by k_trace_mesh.
+template <bool kPark>
 __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, RayQueue q, uint32_t n, int uniform_side, HitBuf h, RayOrder ord, Counters *cnt)
 {
-    __shared__ bhrt_bvh_node nodelet[BHRT_LDS_NODES]; // top BVH levels of the mesh being traversed (device_trace.h)
+    __shared__ bhrt_bvh_node nodelet[kPark ? 1 : BHRT_LDS_NODES]; // top BVH levels of the mesh being traversed (device_trace.h)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = i < n;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
@@ -176,41 +217,73 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, RayQueue q
     const int side = q.meta ? (int)((meta >> 4) & 3u) : uniform_side;
     const bool dead = q.meta && (meta & 15u) == RK_DEAD;
     Hit hit;
-    trace_closest(S, o, d, side, hit, active && !dead, nodelet); // uniform call: the block stages nodelets together
-    if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; }
+    uint32_t key = 0;
+    const int parked = trace_closest(S, o, d, side, hit, active && !dead, kPark ? nullptr : nodelet, 0, kPark, kPark ? &key : nullptr); // uniform call: the block stages nodelets together
+    if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front | ((parked + 1) << 8); }
+    if (kPark && parked >= 0) ord.park_key[i] = key;
     if (!ord.idx) return; // public trace API: no shading order wanted (uniform)
-    // ---- file the ray under its shading class (device_types.h::RayOrder); same predicate as k_shade's `new_frame`
     uint32_t cls = RC_NONE;
-    if (active && !dead) {
-        const uint32_t kind = meta & 15u;
-        const bool is_hit = hit.node >= 0;
-        bool heavy = false;
-        if (is_hit) {
-            if (kind == RK_CAMERA) heavy = true;
-            else if (kind == RK_GI) heavy = fabsf(hit.t) > BHRT_BIAS;
-            else if (kind == RK_REFR_IN) heavy = hit.front != 0;
-            else heavy = true;
-        }
-        cls = heavy ? RC_HEAVY : ((kind == RK_REFR_IN && is_hit) ? RC_MEDIUM : RC_LIGHT);
+    if (active && !dead) cls = parked >= 0 ? (uint32_t)RC_MESH : shading_class(meta, hit);
+    file_ray(cls, i, (i >> 10) & (BHRT_ORDER_SHARDS - 1) /* 16 consecutive waves share a shard: keeps camera-ray neighbourhoods together */, ord, cnt);
+}
+// Workgroup -> slice of the parked list RC_MESH (32 shard segments, each padded to whole workgroups; table by k_mesh_prefix)
+__device__ inline bool parked_entry(const RayOrder &ord, uint32_t *s_seg, uint32_t &i)
+{
+    if (threadIdx.x < 64) {
+        const uint32_t l = threadIdx.x;
+        const uint32_t a = l <= BHRT_ORDER_SHARDS ? ord.mesh_start[l] : 0xffffffffu;
+        const uint32_t n_le = (uint32_t)__popcll(__ballot(l < BHRT_ORDER_SHARDS && a <= blockIdx.x));
+        if (l == 0) *s_seg = n_le - 1;
     }
-    const uint32_t lane = __lane_id();
-    const uint64_t lt = (1ull << lane) - 1ull;
-    const uint32_t shard = (i >> 10) & (BHRT_ORDER_SHARDS - 1); // 16 consecutive waves share a shard: keeps camera-ray neighbourhoods together
-    const uint64_t m0 = __ballot(cls == RC_HEAVY), m1 = __ballot(cls == RC_MEDIUM), m2 = __ballot(cls == RC_LIGHT);
-    uint32_t base = 0;
-    if (lane < 3) { // lanes 0..2 reserve room for classes 0..2
-        const uint64_t mk = lane == 0 ? m0 : (lane == 1 ? m1 : m2);
-        const uint32_t c = (uint32_t)__popcll(mk);
-        if (c) base = atomicAdd(&cnt->cls[lane][shard].v, c);
+    __syncthreads();
+    if (blockIdx.x >= ord.mesh_start[BHRT_ORDER_SHARDS]) return false; // uniform per workgroup: beyond the last segment
+    const uint32_t seg = *s_seg;
+    const uint32_t local = (blockIdx.x - ord.mesh_start[seg]) * kBlock + threadIdx.x;
+    const bool active = local < ord.mesh_count[seg];
+    i = active ? ord.idx[((size_t)RC_MESH * BHRT_ORDER_SHARDS + seg) * ord.shard_cap + local] : 0xffffffffu;
+    return true;
+}
+// counting sort of the parked rays by coherence key: histogram, (scan: k_scan_*), scatter
+__global__ void __launch_bounds__(kBlock) k_park_count(RayOrder ord)
+{
+    __shared__ uint32_t s_seg;
+    uint32_t i;
+    if (!parked_entry(ord, &s_seg, i)) return;
+    if (i != 0xffffffffu) atomicAdd(&ord.park_bucket[ord.park_key[i]], 1u);
+}
+__global__ void __launch_bounds__(kBlock) k_park_scatter(RayOrder ord)
+{
+    __shared__ uint32_t s_seg;
+    uint32_t i;
+    if (!parked_entry(ord, &s_seg, i)) return;
+    if (i != 0xffffffffu) ord.park_sorted[atomicAdd(&ord.park_bucket[ord.park_key[i]], 1u)] = i;
+}
+// The parked rays in key order, one dense workgroup per kBlock of them: resume at the mesh node, finish the scene
+// graph, file the ray under its shading class (shard = workgroup mod 32: k_trace_closest left room for that, see
+// EnsureWorkspace).
+__global__ void __launch_bounds__(kBlock) k_trace_mesh(DevScene S, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
+{
+    __shared__ bhrt_bvh_node nodelet[BHRT_LDS_NODES];
+    const uint32_t total = ord.mesh_count[BHRT_ORDER_SHARDS];
+    if (blockIdx.x * kBlock >= total) return; // uniform per workgroup
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = k < total;
+    const uint32_t i = active ? ord.park_sorted[k] : 0u;
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
+    uint32_t meta = 0;
+    Hit hit = {BHRT_BIGFLOAT, -1, -1, 1};
+    int start = 0;
+    if (active) {
+        o = v3(q.ox[i], q.oy[i], q.oz[i]); d = v3(q.dx[i], q.dy[i], q.dz[i]);
+        meta = q.meta[i];
+        hit.t = h.t[i]; hit.node = h.node[i]; hit.prim = h.prim[i];
+        const int fw = h.front[i];
+        hit.front = fw & 0xff;
+        start = (fw >> 8) - 1;
     }
-    // broadcast the three bases with ALL lanes executing the shuffles (a lane-0..2 ray may itself be classless)
-    const uint32_t b0 = __shfl(base, 0), b1 = __shfl(base, 1), b2 = __shfl(base, 2);
-    if (cls != RC_NONE) {
-        const uint64_t mm = cls == RC_HEAVY ? m0 : (cls == RC_MEDIUM ? m1 : m2);
-        const uint32_t pos = (cls == RC_HEAVY ? b0 : (cls == RC_MEDIUM ? b1 : b2)) + (uint32_t)__popcll(mm & lt);
-        if (pos < ord.shard_cap) ord.idx[((size_t)cls * BHRT_ORDER_SHARDS + shard) * ord.shard_cap + pos] = i;
-        else atomicOr(&cnt->overflow.v, 8u);
-    }
+    trace_closest(S, o, d, (int)((meta >> 4) & 3u), hit, active, nodelet, active ? start : S.n_nodes, false);
+    if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; }
+    file_ray(active ? shading_class(meta, hit) : (uint32_t)RC_NONE, i, blockIdx.x & (BHRT_ORDER_SHARDS - 1), ord, cnt);
 }
 
 // frame == nullptr: visibility goes to vis[i] (public bhrt_trace_shadow_*), else to vis[frame[i]]
@@ -221,6 +294,25 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(DevScene S, ShadowQueue
     const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]), d = v3(q.dx[i], q.dy[i], q.dz[i]);
     const float v = trace_shadow(S, o, d, q.tmax[i]);
     vis[q.frame ? q.frame[i] : i] = v;
+}
+
+// segment table of the parked mesh rays for k_trace_mesh: 32 shards, one lane each
+__global__ void __launch_bounds__(64) k_mesh_prefix(Counters *cnt, RayOrder ord)
+{
+    const uint32_t s = threadIdx.x;
+    uint32_t c = 0;
+    if (s < BHRT_ORDER_SHARDS) {
+        c = cnt->cls[RC_MESH][s].v;
+        cnt->cls[RC_MESH][s].v = 0;
+        if (c > ord.shard_cap) c = ord.shard_cap;
+    }
+    const uint32_t blocks = (c + kBlock - 1) / kBlock;
+    uint32_t incl = blocks;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if ((int)s >= off) incl += t; }
+    uint32_t tot = c;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(tot, off); if ((int)s >= off) tot += t; }
+    if (s < BHRT_ORDER_SHARDS) { ord.mesh_start[s] = incl - blocks; ord.mesh_count[s] = c; }
+    if (s == BHRT_ORDER_SHARDS - 1) { ord.mesh_start[BHRT_ORDER_SHARDS] = incl; ord.mesh_count[BHRT_ORDER_SHARDS] = tot; }
 }
 
 // segment table of the shading order for k_shade (one tiny workgroup per wave step)
@@ -920,9 +1012,10 @@ struct DeviceState {
     uint64_t *d_fcode = nullptr;               // cap_frames
     float *d_ff = nullptr;                     // (3*7 + 2) * cap_frames
     float *d_samples = nullptr;                // 3 * cap_samples
-    uint32_t *d_order = nullptr;               // 3 * BHRT_ORDER_SHARDS * order_shard_cap (shading order, device_types.h::RayOrder)
+    uint32_t *d_order = nullptr;               // 4 * BHRT_ORDER_SHARDS * order_shard_cap (shading order, device_types.h::RayOrder)
     uint32_t order_shard_cap = 0;
-    uint32_t *d_seg = nullptr;                 // seg_start[97] + seg_count[96]
+    uint32_t *d_seg = nullptr;                 // seg_start[97] + seg_count[96] + mesh_start[33] + mesh_count[33]
+    uint32_t *d_park = nullptr;                // park_key[cap_rays] + park_sorted[cap_rays] + buckets + tile sums (RayOrder)
     Counters *d_cnt = nullptr;
     Counters *h_cnt = nullptr; // pinned
     hipStream_t stream = nullptr;
@@ -960,7 +1053,7 @@ void DestroyDeviceState(DeviceState *d)
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(d->d_blob); fr(d->d_chain);
     for (int k = 0; k < 2; k++) { fr(d->d_rayf[k]); fr(d->d_rayu[k]); }
-    fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_seg); fr(d->d_cnt);
+    fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_park); fr(d->d_seg); fr(d->d_cnt);
     fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_cells); fr(d->d_tile_sums);
     if (d->h_n_heavy) (void)hipHostFree(d->h_n_heavy);
     if (d->h_cnt) (void)hipHostFree(d->h_cnt);
@@ -990,8 +1083,8 @@ static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, uint32_t frames
     if (D->cap_samples >= cap_samples && D->cap_frames >= cap_samples * frames_per_sample) return BHRT_OK;
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     for (int k = 0; k < 2; k++) { fr(D->d_rayf[k]); fr(D->d_rayu[k]); D->d_rayf[k] = nullptr; D->d_rayu[k] = nullptr; }
-    fr(D->d_hitf); fr(D->d_hiti); fr(D->d_shf); fr(D->d_shu); fr(D->d_fu); fr(D->d_fcode); fr(D->d_ff); fr(D->d_samples); fr(D->d_order);
-    D->d_order = nullptr;
+    fr(D->d_hitf); fr(D->d_hiti); fr(D->d_shf); fr(D->d_shu); fr(D->d_fu); fr(D->d_fcode); fr(D->d_ff); fr(D->d_samples); fr(D->d_order); fr(D->d_park);
+    D->d_order = nullptr; D->d_park = nullptr;
     D->d_hitf = nullptr; D->d_hiti = nullptr; D->d_shf = nullptr; D->d_shu = nullptr; D->d_fu = nullptr; D->d_fcode = nullptr; D->d_ff = nullptr; D->d_samples = nullptr;
     D->cap_samples = 0;
     const size_t cr = (size_t)cap_samples * 2, cf = (size_t)cap_samples * frames_per_sample;
@@ -1007,8 +1100,11 @@ static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, uint32_t frames
     HIP_CHECK(hipMalloc(&D->d_fcode, cf * sizeof(uint64_t)));
     HIP_CHECK(hipMalloc(&D->d_ff, cf * 23 * sizeof(float)));
     HIP_CHECK(hipMalloc(&D->d_samples, (size_t)cap_samples * 3 * sizeof(float)));
-    D->order_shard_cap = (uint32_t)((((cr + 1023) / 1024 + BHRT_ORDER_SHARDS - 1) / BHRT_ORDER_SHARDS) * 1024 + 1024); // rays [1024 g, 1024 g + 1024) file under shard g mod 32
-    HIP_CHECK(hipMalloc(&D->d_order, (size_t)3 * BHRT_ORDER_SHARDS * D->order_shard_cap * sizeof(uint32_t)));
+    // rays [1024 g, 1024 g + 1024) file under shard g mod 32 (k_trace_closest); k_trace_mesh files its workgroups round-robin:
+    // at most (all parked rays) / 32 + one workgroup more per shard -> twice the even share always fits
+    D->order_shard_cap = (uint32_t)(2 * ((((cr + 1023) / 1024 + BHRT_ORDER_SHARDS - 1) / BHRT_ORDER_SHARDS) * 1024 + 1024));
+    HIP_CHECK(hipMalloc(&D->d_order, (size_t)4 * BHRT_ORDER_SHARDS * D->order_shard_cap * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&D->d_park, (2 * cr + (1u << BHRT_PARK_KEY_BITS) + kScanBlock) * sizeof(uint32_t)));
     D->cap_samples = cap_samples; D->cap_rays = (uint32_t)cr; D->cap_frames = (uint32_t)cf;
     if (D->d_ph_frames) { (void)hipFree(D->d_ph_frames); D->d_ph_frames = nullptr; D->ph_frames_cap = 0; }
     return BHRT_OK;
@@ -1214,7 +1310,8 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         HitBuf HB; HB.t = D->d_hitf; HB.node = D->d_hiti; HB.prim = D->d_hiti + D->cap_rays; HB.front = D->d_hiti + 2 * (size_t)D->cap_rays;
         ShadowQueue SQ; { float *p = D->d_shf; const size_t c = D->cap_rays; SQ.ox = p; SQ.oy = p + c; SQ.oz = p + 2 * c; SQ.dx = p + 3 * c; SQ.dy = p + 4 * c; SQ.dz = p + 5 * c; SQ.tmax = p + 6 * c; SQ.frame = D->d_shu; }
         Frames F = MakeFrames(D);
-        RayOrder RO = {D->d_order, D->order_shard_cap, D->d_seg, D->d_seg + 3 * BHRT_ORDER_SHARDS + 1};
+        RayOrder RO = {D->d_order, D->order_shard_cap, D->d_seg, D->d_seg + 3 * BHRT_ORDER_SHARDS + 1, D->d_seg + 6 * BHRT_ORDER_SHARDS + 1, D->d_seg + 7 * BHRT_ORDER_SHARDS + 2,
+                       D->d_park, D->d_park + D->cap_rays, D->d_park + 2 * (size_t)D->cap_rays};
         HIP_CHECK(hipMemsetAsync(D->d_cnt, 0, sizeof(Counters), D->stream));
         HIP_CHECK(hipMemsetAsync(D->d_samples, 0, (size_t)npx * o.spp * 3 * sizeof(float), D->stream));
         const uint32_t total = npx * (uint32_t)o.spp;
@@ -1232,7 +1329,20 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         while (n_cur > 0) {
             {
                 Timer t(D, &st->seconds_trace_closest);
-                hipLaunchKernelGGL(k_trace_closest, dim3((n_cur + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
+                const dim3 tg((n_cur + kBlock - 1) / kBlock), tb(kBlock);
+                if (H->n_meshes > 0) { // park the mesh rays, then finish them in dense workgroups
+                    hipLaunchKernelGGL(k_trace_closest<true>, tg, tb, 0, D->stream, D->S, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
+                    hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
+                    const uint32_t n_buckets = 1u << BHRT_PARK_KEY_BITS, n_tiles = n_buckets / kScanTile;
+                    const dim3 pg(tg.x + BHRT_ORDER_SHARDS);
+                    HIP_CHECK(hipMemsetAsync(RO.park_bucket, 0, n_buckets * sizeof(uint32_t), D->stream));
+                    hipLaunchKernelGGL(k_park_count, pg, tb, 0, D->stream, RO);
+                    hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, RO.park_bucket, n_buckets, RO.park_bucket + n_buckets);
+                    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, D->stream, RO.park_bucket + n_buckets, n_tiles);
+                    hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, RO.park_bucket, n_buckets, RO.park_bucket + n_buckets);
+                    hipLaunchKernelGGL(k_park_scatter, pg, tb, 0, D->stream, RO);
+                    hipLaunchKernelGGL(k_trace_mesh, tg, tb, 0, D->stream, D->S, Q[cur], HB, RO, D->d_cnt);
+                } else hipLaunchKernelGGL(k_trace_closest<false>, tg, tb, 0, D->stream, D->S, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
                 t.Stop();
             }
             st->launches_trace_closest++;
@@ -1347,7 +1457,7 @@ int bhrt_scene_upload(bhrt_scene *scene, int device)
     HIP_CHECK(hipMalloc(&D->d_chain, chain.size() * sizeof(int32_t)));
     HIP_CHECK(hipMemcpy(D->d_chain, chain.data(), chain.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&D->d_cnt, sizeof(Counters)));
-    HIP_CHECK(hipMalloc(&D->d_seg, (6 * BHRT_ORDER_SHARDS + 1) * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&D->d_seg, (8 * BHRT_ORDER_SHARDS + 3) * sizeof(uint32_t)));
     HIP_CHECK(hipHostMalloc(&D->h_cnt, sizeof(Counters)));
     DevScene &S = D->S;
     S.blob = D->d_blob;
@@ -1395,8 +1505,8 @@ int bhrt_trace_closest_dev(bhrt_scene *scene, const float *d_rays_soa, int hit_s
     RayQueue q = MakeRayQueue(const_cast<float *>(d_rays_soa), nullptr, n);
     HitBuf h; h.t = d_out.t; h.node = d_out.node; h.prim = d_out.prim; h.front = d_out.front;
     hipStream_t s = stream ? (hipStream_t)stream : scene->dev->stream;
-    RayOrder no_order = {nullptr, 0, nullptr, nullptr};
-    hipLaunchKernelGGL(k_trace_closest, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, q, (uint32_t)n, hit_side, h, no_order, (Counters *)nullptr);
+    RayOrder no_order = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(k_trace_closest<false>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, q, (uint32_t)n, hit_side, h, no_order, (Counters *)nullptr);
     HIP_CHECK(hipGetLastError());
     if (!stream) HIP_CHECK(hipStreamSynchronize(s));
     return BHRT_OK;

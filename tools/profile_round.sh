@@ -1,0 +1,15 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): the rocprofv3 evidence of one round.  Usage: tools/profile_round.sh <tag> [workload]
+# Writes under gpurun_out/<tag>/; tools/pmc_summary.py turns that into the files committed under profiles/.
+# The counter passes are separate runs with --pmc only (no trace domains), as the pool requires.
+set -e
+TAG=${1:-r01}; WL=${2:-c2}
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $OUT/trace_$WL -o $WL --output-format csv -- python3 $R/bench.py --workload $WL --no-cpu-baseline > $OUT/trace_$WL.log 2>&1
+tail -1 $OUT/trace_$WL.log > $OUT/bench_under_rocprof_$WL.json
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$WL -o p --output-format csv -- python3 $R/tools/pmc_workload.py $WL > $OUT/pmc_fetch_$WL.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_$WL -o p --output-format csv -- python3 $R/tools/pmc_workload.py $WL > $OUT/pmc_write_$WL.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d $OUT/pmc_sq_$WL -o p --output-format csv -- python3 $R/tools/pmc_workload.py $WL > $OUT/pmc_sq_$WL.log 2>&1
+echo done $TAG $WL
