@@ -1,7 +1,7 @@
 // kernels.hip — the MI355X (gfx950) render path: wavefront path tracing over SoA buffers in HBM.
 //
 // One launch of each kernel processes one "wave step" of all paths in flight:
-//   k_camera_rays   Main.cpp:132-153,179-192   one lane per (pixel, sample) -> closest-hit ray queue
+//   camera_ray()    Main.cpp:132-153,179-192   the camera ray of a (pixel, sample) slot, computed inside the first step's kernels
 //   k_trace_closest Main.cpp:389-413 + Objects/* ordered scene-graph + BVH closest hit -> compact hits
 //   k_shade         MtlBlinn.cpp:89-589        one lane per traced ray: rebuilds the HitInfo, evaluates one
 //                                              Shade() entry or one refraction-chain step, emits <=2 closest rays,
@@ -127,37 +127,43 @@ __device__ inline void st3(float *a, uint32_t i, V3 v) { a[3 * (size_t)i] = v.x;
 __device__ inline V3 ld3i(const float *a, uint32_t i) { return v3(a[3 * (size_t)i], a[3 * (size_t)i + 1], a[3 * (size_t)i + 2]); }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_camera_rays(DevScene S, PassInfo P, RayQueue q)
+// The camera ray of slot idx = (pixel of the pass, sample): PathTracing + RandomPositionInPixel (Main.cpp:132-153).
+// Camera rays are never stored: the first wave step's kernels (k_trace_closest / k_trace_mesh / k_shade with
+// kCamera) each call this — ~300 VALU instructions instead of a 36-byte record written once and read twice.
+// false: the slot is a pixel of an edge tile outside the image (a dead ray).
+__device__ inline bool camera_ray(const DevScene &S, const PassInfo &P, uint32_t idx, V3 &o, V3 &d)
 {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t total = P.n_pixels * (uint32_t)P.spp;
-    bool valid = idx < total;
     int i = 0, j = 0;
-    uint32_t s = 0;
-    if (valid) {
-        const uint32_t q_local = idx / (uint32_t)P.spp;
-        s = idx % (uint32_t)P.spp;
-        valid = pixel_of(P, P.q0 + q_local, i, j);
+    const uint32_t q_local = idx / (uint32_t)P.spp, s = idx % (uint32_t)P.spp;
+    o = v3(0, 0, 0); d = v3(0, 0, 0);
+    if (!pixel_of(P, P.q0 + q_local, i, j)) return false;
+    // PathTracing(), Main.cpp:145: pixel "centre" = corner because 1/2 == 0
+    const V3 topLeft = ld3(S.cam.top_left), ddx = ld3(S.cam.dd_x), ddy = ld3(S.cam.dd_y), pos = ld3(S.cam.pos);
+    V3 target = (topLeft + (float)i * ddx) - (float)j * ddy;
+    if (P.jitter) { // RandomPositionInPixel, Main.cpp:132-139: two raw rand() draws in double
+        const float pixelLen = length(ddx);
+        const V3 ux = normalized(ddx), uy = normalized(ddy);
+        const uint32_t key = bhrt_sample_key(P.seed, (uint32_t)(j * P.W + i), s);
+        float fx = (float)(((double)bhrt_rand31(key, 0) / (BHRT_RAND_MAX)) * 2 - 1);
+        target = target + ((ux * fx) * pixelLen) / 2.f;
+        float fy = (float)(((double)bhrt_rand31(key, 1) / (BHRT_RAND_MAX)) * 2 - 1);
+        target = target + ((uy * fy) * pixelLen) / 2.f;
     }
-    V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
-    if (valid) {
-        // PathTracing(), Main.cpp:145: pixel "centre" = corner because 1/2 == 0
-        const V3 topLeft = ld3(S.cam.top_left), ddx = ld3(S.cam.dd_x), ddy = ld3(S.cam.dd_y), pos = ld3(S.cam.pos);
-        V3 target = (topLeft + (float)i * ddx) - (float)j * ddy;
-        if (P.jitter) { // RandomPositionInPixel, Main.cpp:132-139: two raw rand() draws in double
-            const float pixelLen = length(ddx);
-            const V3 ux = normalized(ddx), uy = normalized(ddy);
-            const uint32_t key = bhrt_sample_key(P.seed, (uint32_t)(j * P.W + i), s);
-            float fx = (float)(((double)bhrt_rand31(key, 0) / (BHRT_RAND_MAX)) * 2 - 1);
-            target = target + ((ux * fx) * pixelLen) / 2.f;
-            float fy = (float)(((double)bhrt_rand31(key, 1) / (BHRT_RAND_MAX)) * 2 - 1);
-            target = target + ((uy * fy) * pixelLen) / 2.f;
-        }
-        o = pos;
-        d = target - pos;
+    o = pos;
+    d = target - pos;
+    return true;
+}
+// one queued ray, or (kCamera) the camera ray of slot i: one slot per (pixel, sample), no compaction
+template <bool kCamera>
+__device__ inline void fetch_ray(const DevScene &S, const PassInfo &P, const RayQueue &q, uint32_t i, V3 &o, V3 &d, uint32_t &meta)
+{
+    if (kCamera) {
+        const bool valid = camera_ray(S, P, i, o, d);
+        meta = make_meta(valid ? RK_CAMERA : RK_DEAD, BHRT_HIT_FRONT, 0);
+    } else {
+        o = v3(q.ox[i], q.oy[i], q.oz[i]); d = v3(q.dx[i], q.dy[i], q.dz[i]);
+        meta = q.meta ? q.meta[i] : 0u;
     }
-    // one slot per (pixel, sample), no compaction: out-of-image pixels of edge tiles become dead rays
-    if (idx < total) put_ray(q, idx, o, d, idx, make_meta(valid ? RK_CAMERA : RK_DEAD, BHRT_HIT_FRONT, 0), 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -202,20 +208,18 @@ __device__ inline uint32_t shading_class(uint32_t meta, const Hit &hit)
 // Closest hit of every queued ray.  meta == nullptr: every ray uses `uniform_side` (public bhrt_trace_closest_*).
 // kPark (scenes with meshes, render path): rays that reach a mesh whose root box they hit are parked on list RC_MESH
 // with their state in the hit buffer (front = front | (node + 1) << 8) and finished by k_trace_mesh.
-template <bool kPark>
-__global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, RayQueue q, uint32_t n, int uniform_side, HitBuf h, RayOrder ord, Counters *cnt)
+template <bool kPark, bool kCamera>
+__global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, PassInfo P, RayQueue q, uint32_t n, int uniform_side, HitBuf h, RayOrder ord, Counters *cnt)
 {
     __shared__ bhrt_bvh_node nodelet[kPark ? 1 : BHRT_LDS_NODES]; // top BVH levels of the mesh being traversed (device_trace.h)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = i < n;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
     uint32_t meta = 0;
-    if (active) {
-        o = v3(q.ox[i], q.oy[i], q.oz[i]); d = v3(q.dx[i], q.dy[i], q.dz[i]);
-        meta = q.meta ? q.meta[i] : 0u;
-    }
-    const int side = q.meta ? (int)((meta >> 4) & 3u) : uniform_side;
-    const bool dead = q.meta && (meta & 15u) == RK_DEAD;
+    if (active) fetch_ray<kCamera>(S, P, q, i, o, d, meta);
+    const bool has_meta = kCamera || q.meta;
+    const int side = has_meta ? (int)((meta >> 4) & 3u) : uniform_side;
+    const bool dead = has_meta && (meta & 15u) == RK_DEAD;
     Hit hit;
     uint32_t key = 0;
     const int parked = trace_closest(S, o, d, side, hit, active && !dead, kPark ? nullptr : nodelet, 0, kPark, kPark ? &key : nullptr); // uniform call: the block stages nodelets together
@@ -261,7 +265,8 @@ __global__ void __launch_bounds__(kBlock) k_park_scatter(RayOrder ord)
 // The parked rays in key order, one dense workgroup per kBlock of them: resume at the mesh node, finish the scene
 // graph, file the ray under its shading class (shard = workgroup mod 32: k_trace_closest left room for that, see
 // EnsureWorkspace).
-__global__ void __launch_bounds__(kBlock) k_trace_mesh(DevScene S, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
+template <bool kCamera>
+__global__ void __launch_bounds__(kBlock) k_trace_mesh(DevScene S, PassInfo P, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
 {
     __shared__ bhrt_bvh_node nodelet[BHRT_LDS_NODES];
     const uint32_t total = ord.mesh_count[BHRT_ORDER_SHARDS];
@@ -274,8 +279,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_mesh(DevScene S, RayQueue q, H
     Hit hit = {BHRT_BIGFLOAT, -1, -1, 1};
     int start = 0;
     if (active) {
-        o = v3(q.ox[i], q.oy[i], q.oz[i]); d = v3(q.dx[i], q.dy[i], q.dz[i]);
-        meta = q.meta[i];
+        fetch_ray<kCamera>(S, P, q, i, o, d, meta);
         hit.t = h.t[i]; hit.node = h.node[i]; hit.prim = h.prim[i];
         const int fw = h.front[i];
         hit.front = fw & 0xff;
@@ -480,6 +484,7 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
     F.info[f] = (F.info[f] & 7u) | (dmode << 3) | (light_idx << 8) | (flags << 16) | ((uint32_t)(mi & 0xfff) << 20);
 }
 
+template <bool kCamera>
 __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene S, RenderParams R, PassInfo P, RayQueue qin, HitBuf hb, uint32_t n, RayQueue qout,
                                                    ShadowQueue qs, Frames F, float *samples, Counters *cnt, RayOrder ord)
 {
@@ -507,12 +512,12 @@ __global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene S, RenderParams 
     uint32_t owner = 0, meta = 0, ctr = 0;
     Hit hit = {BHRT_BIGFLOAT, -1, -1, 1};
     if (active) {
-        meta = qin.meta[i];
+        fetch_ray<kCamera>(S, P, qin, i, o, d, meta);
         active = (meta & 15u) != RK_DEAD;
     }
     if (active) {
-        o = v3(qin.ox[i], qin.oy[i], qin.oz[i]); d = v3(qin.dx[i], qin.dy[i], qin.dz[i]);
-        owner = qin.frame[i]; ctr = qin.rng_ctr[i];
+        if (kCamera) { owner = i; ctr = 0; } // the sample slot
+        else { owner = qin.frame[i]; ctr = qin.rng_ctr[i]; }
         hit.t = hb.t[i]; hit.node = hb.node[i]; hit.prim = hb.prim[i]; hit.front = hb.front[i];
     }
     const uint32_t kind = meta & 15u;
@@ -1315,12 +1320,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         HIP_CHECK(hipMemsetAsync(D->d_cnt, 0, sizeof(Counters), D->stream));
         HIP_CHECK(hipMemsetAsync(D->d_samples, 0, (size_t)npx * o.spp * 3 * sizeof(float), D->stream));
         const uint32_t total = npx * (uint32_t)o.spp;
-        {
-            Timer t(D, &st->seconds_other);
-            hipLaunchKernelGGL(k_camera_rays, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, P, Q[0]);
-            t.Stop();
-        }
-        uint32_t n_cur = total;
+        uint32_t n_cur = total; // first wave step: one slot per (pixel, sample); the kernels compute the camera rays themselves
         bool first_step = true;
         int cur = 0;
         std::vector<uint32_t> frame_marks = {0};
@@ -1331,7 +1331,8 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 Timer t(D, &st->seconds_trace_closest);
                 const dim3 tg((n_cur + kBlock - 1) / kBlock), tb(kBlock);
                 if (H->n_meshes > 0) { // park the mesh rays, then finish them in dense workgroups
-                    hipLaunchKernelGGL(k_trace_closest<true>, tg, tb, 0, D->stream, D->S, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
+                    if (first_step) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<true, true>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<true, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
                     hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
                     const uint32_t n_buckets = 1u << BHRT_PARK_KEY_BITS, n_tiles = n_buckets / kScanTile;
                     const dim3 pg(tg.x + BHRT_ORDER_SHARDS);
@@ -1341,15 +1342,19 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, D->stream, RO.park_bucket + n_buckets, n_tiles);
                     hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, RO.park_bucket, n_buckets, RO.park_bucket + n_buckets);
                     hipLaunchKernelGGL(k_park_scatter, pg, tb, 0, D->stream, RO);
-                    hipLaunchKernelGGL(k_trace_mesh, tg, tb, 0, D->stream, D->S, Q[cur], HB, RO, D->d_cnt);
-                } else hipLaunchKernelGGL(k_trace_closest<false>, tg, tb, 0, D->stream, D->S, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
+                    if (first_step) hipLaunchKernelGGL(k_trace_mesh<true>, tg, tb, 0, D->stream, D->S, P, Q[cur], HB, RO, D->d_cnt);
+                    else hipLaunchKernelGGL(k_trace_mesh<false>, tg, tb, 0, D->stream, D->S, P, Q[cur], HB, RO, D->d_cnt);
+                } else if (first_step) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, true>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
                 t.Stop();
             }
             st->launches_trace_closest++;
             hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(128), 0, D->stream, D->d_cnt, RO);
             {
                 Timer t(D, &st->seconds_shade);
-                hipLaunchKernelGGL(k_shade, dim3((n_cur + kShadeBlock - 1) / kShadeBlock + 3 * BHRT_ORDER_SHARDS), dim3(kShadeBlock), 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt, RO);
+                const dim3 sg((n_cur + kShadeBlock - 1) / kShadeBlock + 3 * BHRT_ORDER_SHARDS), sb(kShadeBlock);
+                if (first_step) hipLaunchKernelGGL(k_shade<true>, sg, sb, 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt, RO);
+                else hipLaunchKernelGGL(k_shade<false>, sg, sb, 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt, RO);
                 t.Stop();
             }
             HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, BHRT_COUNTERS_HOST_BYTES, hipMemcpyDeviceToHost, D->stream)); // n_next, n_shadow, n_frames, overflow
@@ -1506,7 +1511,7 @@ int bhrt_trace_closest_dev(bhrt_scene *scene, const float *d_rays_soa, int hit_s
     HitBuf h; h.t = d_out.t; h.node = d_out.node; h.prim = d_out.prim; h.front = d_out.front;
     hipStream_t s = stream ? (hipStream_t)stream : scene->dev->stream;
     RayOrder no_order = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(k_trace_closest<false>, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, q, (uint32_t)n, hit_side, h, no_order, (Counters *)nullptr);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, false>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, PassInfo(), q, (uint32_t)n, hit_side, h, no_order, (Counters *)nullptr);
     HIP_CHECK(hipGetLastError());
     if (!stream) HIP_CHECK(hipStreamSynchronize(s));
     return BHRT_OK;
