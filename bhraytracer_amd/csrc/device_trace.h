@@ -200,37 +200,22 @@ __device__ inline uint32_t node_data(const MeshRef &M, uint32_t i) { return i < 
 //     from the SECOND-visited child: return (first child's r) ? true : r
 //   children are adjacent and the first child's id is even (cyBVH.h:281-291), so sibling = id ^ 1.
 // Trail: bit (depth-1) of inFar / nearHit per level; depth <= 64 is checked at upload.
-// The traversal is an object (begin / round) so that a kernel can interleave it with other work; mesh_closest() below
-// is the plain "run to the end" form.
-struct MeshTrav {
-    V3 o, d;
-    RayRcp rr;
-    float dlen;
-    int side;
-    uint32_t cur, data;
-    int depth;
-    uint64_t inFar, nearHit;
-    bool desc, r, any, alive;
-    float ht;
-    int hprim, hfront;
-
-    // root box gate of TriObj::IntersectRay; ht/hprim/hfront = the hit so far
-    __device__ void begin(const MeshRef &M, V3 o_, V3 d_, int side_, float ht_, int hprim_, int hfront_)
-    {
-        o = o_; d = d_; side = side_; ht = ht_; hprim = hprim_; hfront = hfront_;
-        rr = ray_rcp(d);
-        any = false; r = false; desc = true; cur = 1; depth = 0; inFar = 0; nearHit = 0;
-        float tm;
-        const NodeRec root = node_at(M, 1);
-        data = root.data;
-        alive = box_hit_rcp(root.b, o, d, rr, ht, tm);
-        dlen = length(d);
-    }
-    // One round of the "while-while" form of the state machine: the lanes of a wave run the three phases together
-    // (descend through inner nodes / test a leaf / climb), so a wave executes max-per-phase work instead of the union
-    // of all three bodies on every step.  Call only while alive.
-    __device__ void round(const MeshRef &M)
-    {
+__device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront)
+{
+    float tm;
+    const RayRcp rr = ray_rcp(d);
+    const NodeRec root = node_at(M, 1);
+    if (!box_hit_rcp(root.b, o, d, rr, ht, tm)) return false;
+    const float dlen = length(d);
+    uint32_t cur = 1;
+    int depth = 0;
+    uint64_t inFar = 0, nearHit = 0;
+    bool desc = true, r = false, any = false;
+    uint32_t data = root.data;
+    // "while-while" form of the state machine: the lanes of a wave run the three phases together (descend through
+    // inner nodes / test a leaf / climb), so a wave executes max-per-phase work instead of the union of all
+    // three bodies on every step.
+    while (true) {
         // ---- phase 1: descend through inner nodes
         while (desc && !(data & 0x80000000u)) {
             const uint32_t c1 = data & 0x7fffffffu;
@@ -287,16 +272,9 @@ struct MeshTrav {
                 depth--;
             }
         }
-        if (!desc) alive = false; // depth == 0: the root call returned
+        if (!desc) break; // depth == 0: the root call returned
     }
-};
-__device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront)
-{
-    MeshTrav T;
-    T.begin(M, o, d, side, ht, hprim, hfront);
-    while (T.alive) T.round(M);
-    ht = T.ht; hprim = T.hprim; hfront = T.hfront;
-    return T.any;
+    return any;
 }
 
 // TriObj::ShadowRecursive + TraceBVHShadow (TriObj.cpp:41-66,272-307): pre-order walk (child1 then child2 — the
@@ -465,13 +443,18 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
 
 // GenLight::Shadow (GenLight.cpp:10-69).  The result is an OR over per-node tests that do not influence each
 // other, so nodes are tested in index order; each test is the reference's (including its quirks Q1-Q3).
-__device__ inline float trace_shadow(const DevScene &S, V3 o, V3 d, float t_max)
+// kMode 0: everything.  kMode 1: spheres and planes only; returns 2.f instead of 1.f when the ray also hits the root
+// box of a mesh (the caller parks it for k_shadow_mesh).  kMode 2: the meshes only.
+template <int kMode>
+__device__ inline float trace_shadow_t(const DevScene &S, V3 o, V3 d, float t_max)
 {
     V3 rp = o, rd = d;
     to_node_identity(rp, rd); // rootNode's own ToNodeCoords
+    bool wants_mesh = false;
     for (int n = 0; n < S.n_nodes; n++) {
         const int type = S.nodes[n].obj_type;
         if (type == BHRT_OBJ_NONE) continue;
+        if (kMode == 2 && type != BHRT_OBJ_MESH) continue;
         const int depth = S.nodes[n].depth;
         const int32_t *ch = S.chain + (size_t)n * BHRT_MAX_NODE_DEPTH;
         V3 pp = rp, pd = rd; // ray in the PARENT's space (used by the plane test, Q1)
@@ -497,11 +480,15 @@ __device__ inline float trace_shadow(const DevScene &S, V3 o, V3 d, float t_max)
                 if (!(x.x < -1 || x.x > 1 || x.y < -1 || x.y > 1))
                     if (t < t_max && t > BHRT_SHADOW_BIAS) return 0.f;
             }
+        } else if (kMode == 1) {
+            float tm; // the root box gate of TriObj::ShadowRecursive (TriObj.cpp:41-54), repeated by mesh_shadow
+            if (!wants_mesh && box_hit_rcp(node_at(mesh_ref(S, S.nodes[n].mesh), 1).b, lp, ld, ray_rcp(ld), BHRT_BIGFLOAT, tm)) wants_mesh = true;
         } else {
             if (mesh_shadow(mesh_ref(S, S.nodes[n].mesh), lp, ld, t_max)) return 0.f;
         }
     }
-    return 1.f;
+    return wants_mesh ? 2.f : 1.f;
 }
+__device__ inline float trace_shadow(const DevScene &S, V3 o, V3 d, float t_max) { return trace_shadow_t<0>(S, o, d, t_max); }
 
 } // namespace bhrt

@@ -230,37 +230,41 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, PassInfo P
     if (active && !dead) cls = parked >= 0 ? (uint32_t)RC_MESH : shading_class(meta, hit);
     file_ray(cls, i, (i >> 10) & (BHRT_ORDER_SHARDS - 1) /* 16 consecutive waves share a shard: keeps camera-ray neighbourhoods together */, ord, cnt);
 }
-// Workgroup -> slice of the parked list RC_MESH (32 shard segments, each padded to whole workgroups; table by k_mesh_prefix)
-__device__ inline bool parked_entry(const RayOrder &ord, uint32_t *s_seg, uint32_t &i)
+// Slice `b` (kBlock entries) of the parked list RC_MESH (32 shard segments, each padded to whole slices; table by
+// k_mesh_prefix).  Called by a whole workgroup; false = b is beyond the last slice (uniform).
+__device__ inline bool parked_entry(const RayOrder &ord, uint32_t b, uint32_t *s_seg, uint32_t &i)
 {
+    __syncthreads(); // *s_seg of the previous slice no longer in use
     if (threadIdx.x < 64) {
         const uint32_t l = threadIdx.x;
         const uint32_t a = l <= BHRT_ORDER_SHARDS ? ord.mesh_start[l] : 0xffffffffu;
-        const uint32_t n_le = (uint32_t)__popcll(__ballot(l < BHRT_ORDER_SHARDS && a <= blockIdx.x));
+        const uint32_t n_le = (uint32_t)__popcll(__ballot(l < BHRT_ORDER_SHARDS && a <= b));
         if (l == 0) *s_seg = n_le - 1;
     }
     __syncthreads();
-    if (blockIdx.x >= ord.mesh_start[BHRT_ORDER_SHARDS]) return false; // uniform per workgroup: beyond the last segment
+    if (b >= ord.mesh_start[BHRT_ORDER_SHARDS]) return false;
     const uint32_t seg = *s_seg;
-    const uint32_t local = (blockIdx.x - ord.mesh_start[seg]) * kBlock + threadIdx.x;
+    const uint32_t local = (b - ord.mesh_start[seg]) * kBlock + threadIdx.x;
     const bool active = local < ord.mesh_count[seg];
     i = active ? ord.idx[((size_t)RC_MESH * BHRT_ORDER_SHARDS + seg) * ord.shard_cap + local] : 0xffffffffu;
     return true;
 }
-// counting sort of the parked rays by coherence key: histogram, (scan: k_scan_*), scatter
+// counting sort of the parked rays by coherence key: histogram, (scan: k_scan_*), scatter.  A fixed grid strides over
+// the slices: the number of parked rays is only known on the device, and a grid sized for "all rays parked" spends
+// most of a launch retiring empty workgroups.
 __global__ void __launch_bounds__(kBlock) k_park_count(RayOrder ord)
 {
     __shared__ uint32_t s_seg;
     uint32_t i;
-    if (!parked_entry(ord, &s_seg, i)) return;
-    if (i != 0xffffffffu) atomicAdd(&ord.park_bucket[ord.park_key[i]], 1u);
+    for (uint32_t b = blockIdx.x; parked_entry(ord, b, &s_seg, i); b += gridDim.x)
+        if (i != 0xffffffffu) atomicAdd(&ord.park_bucket[ord.park_key[i]], 1u);
 }
 __global__ void __launch_bounds__(kBlock) k_park_scatter(RayOrder ord)
 {
     __shared__ uint32_t s_seg;
     uint32_t i;
-    if (!parked_entry(ord, &s_seg, i)) return;
-    if (i != 0xffffffffu) ord.park_sorted[atomicAdd(&ord.park_bucket[ord.park_key[i]], 1u)] = i;
+    for (uint32_t b = blockIdx.x; parked_entry(ord, b, &s_seg, i); b += gridDim.x)
+        if (i != 0xffffffffu) ord.park_sorted[atomicAdd(&ord.park_bucket[ord.park_key[i]], 1u)] = i;
 }
 // The parked rays in key order, one dense workgroup per kBlock of them: resume at the mesh node, finish the scene
 // graph, file the ray under its shading class (shard = workgroup mod 32: k_trace_closest left room for that, see
@@ -298,6 +302,26 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(DevScene S, ShadowQueue
     const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]), d = v3(q.dx[i], q.dy[i], q.dz[i]);
     const float v = trace_shadow(S, o, d, q.tmax[i]);
     vis[q.frame ? q.frame[i] : i] = v;
+}
+// Scenes with meshes, render path: spheres and planes here; a ray they leave unoccluded that enters a mesh's root box
+// is parked on list RC_MESH and decided by k_shadow_mesh in dense workgroups (same reason as k_trace_mesh).
+__global__ void __launch_bounds__(kBlock) k_trace_shadow_park(DevScene S, ShadowQueue q, uint32_t n, float *vis, RayOrder ord, Counters *cnt)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 1.f;
+    if (i < n) {
+        v = trace_shadow_t<1>(S, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), q.tmax[i]);
+        if (v != 2.f) vis[q.frame[i]] = v;
+    }
+    file_ray(v == 2.f ? (uint32_t)RC_MESH : (uint32_t)RC_NONE, i, (i >> 10) & (BHRT_ORDER_SHARDS - 1), ord, cnt);
+}
+__global__ void __launch_bounds__(kBlock) k_shadow_mesh(DevScene S, ShadowQueue q, float *vis, RayOrder ord)
+{
+    __shared__ uint32_t s_seg;
+    uint32_t i;
+    if (!parked_entry(ord, blockIdx.x, &s_seg, i)) return;
+    if (i == 0xffffffffu) return;
+    vis[q.frame[i]] = trace_shadow_t<2>(S, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), q.tmax[i]);
 }
 
 // segment table of the parked mesh rays for k_trace_mesh: 32 shards, one lane each
@@ -1335,7 +1359,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<true, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
                     hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
                     const uint32_t n_buckets = 1u << BHRT_PARK_KEY_BITS, n_tiles = n_buckets / kScanTile;
-                    const dim3 pg(tg.x + BHRT_ORDER_SHARDS);
+                    const dim3 pg(std::min<uint32_t>(tg.x + BHRT_ORDER_SHARDS, 4096u));
                     HIP_CHECK(hipMemsetAsync(RO.park_bucket, 0, n_buckets * sizeof(uint32_t), D->stream));
                     hipLaunchKernelGGL(k_park_count, pg, tb, 0, D->stream, RO);
                     hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, RO.park_bucket, n_buckets, RO.park_bucket + n_buckets);
@@ -1370,7 +1394,12 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             const uint32_t n_sh = D->h_cnt->n_shadow.v;
             if (n_sh) {
                 Timer t(D, &st->seconds_trace_shadow);
-                hipLaunchKernelGGL(k_trace_shadow, dim3((n_sh + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->S, SQ, n_sh, F.vis);
+                const dim3 hg((n_sh + kBlock - 1) / kBlock), hb(kBlock);
+                if (H->n_meshes > 0) {
+                    hipLaunchKernelGGL(k_trace_shadow_park, hg, hb, 0, D->stream, D->S, SQ, n_sh, F.vis, RO, D->d_cnt);
+                    hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
+                    hipLaunchKernelGGL(k_shadow_mesh, dim3(hg.x + BHRT_ORDER_SHARDS), hb, 0, D->stream, D->S, SQ, F.vis, RO);
+                } else hipLaunchKernelGGL(k_trace_shadow, hg, hb, 0, D->stream, D->S, SQ, n_sh, F.vis);
                 t.Stop();
                 st->shadow_rays += n_sh; st->launches_trace_shadow++;
             }
