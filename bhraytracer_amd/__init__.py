@@ -64,7 +64,7 @@ EXPORTS = [
     "bhrt_scene_warning", "bhrt_scene_flat", "bhrt_scene_upload", "bhrt_device_count",
     "bhrt_trace_closest_host", "bhrt_trace_closest_dev", "bhrt_trace_shadow_host", "bhrt_trace_shadow_dev",
     "bhrt_render", "bhrt_render_dev", "bhrt_render_samples", "bhrt_photon_build", "bhrt_photon_gather_host",
-    "bhrt_photon_get", "bhrt_photon_export", "bhrt_save_png", "bhrt_math_eval_dev",
+    "bhrt_photon_get", "bhrt_photon_export", "bhrt_photon_import", "bhrt_save_png", "bhrt_math_eval_dev",
 ]
 
 
@@ -221,6 +221,10 @@ class Scene:
 
     def photon_export(self, path: str):
         _check(lib().bhrt_photon_export(self._h, os.fsencode(path)))
+
+    def photon_import(self, path: str, rebalance: bool = False):
+        """Loads a .dat of 24-byte records; rebalance=True mirrors PhotonMap::InitializePhotonMapByFile."""
+        _check(lib().bhrt_photon_import(self._h, os.fsencode(path), 1 if rebalance else 0))
 
     def render_samples(self, opts: Opts, x0, y0, x1, y1):
         out = np.zeros(((y1 - y0) * (x1 - x0), opts.spp, 3), np.float32)

@@ -5,6 +5,7 @@
 //
 //   bhrt render <scene.xml> [-o out.png] [--spp N] [--gi N] [--bounces N] [--seed S] [--no-jitter] [--no-gamma]
 //               [--device D] [--rank R --world N --tile T] [--radiance out.f32]
+//               [--photons N] [--photon-file map.dat] [--photon-out map.dat]     (USE_PhotonMap, Main.cpp:51,53,194,383)
 //   bhrt info   <scene.xml>
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,7 +30,8 @@ int main(int argc, char **argv)
     }
     const bool render = !strcmp(argv[1], "render");
     const char *scene_path = argv[2];
-    std::string out = "out.png", radiance_out;
+    std::string out = "out.png", radiance_out, photon_file, photon_out;
+    uint32_t photons = 0;
     bhrt_opts o;
     bhrt_default_opts(&o);
     int device = 0;
@@ -48,6 +50,9 @@ int main(int argc, char **argv)
         else if (s == "--world") o.world_size = atoi(next());
         else if (s == "--tile") o.tile_size = atoi(next());
         else if (s == "--radiance") radiance_out = next();
+        else if (s == "--photons") photons = (uint32_t)strtoul(next(), nullptr, 10);
+        else if (s == "--photon-file") photon_file = next();
+        else if (s == "--photon-out") photon_out = next();
         else { fprintf(stderr, "bhrt: unknown option %s\n", s.c_str()); return 2; }
     }
     bhrt_scene *scene = nullptr;
@@ -65,6 +70,16 @@ int main(int argc, char **argv)
     if (bhrt_scene_upload(scene, device)) return fail("upload");
     std::vector<uint8_t> rgb((size_t)info.width * info.height * 3, 0);
     std::vector<float> rad(radiance_out.empty() ? 0 : (size_t)info.width * info.height * 3, 0.f);
+    if (!photon_file.empty()) { // a cached photon pass
+        if (bhrt_photon_import(scene, photon_file.c_str(), 0)) return fail("photon import");
+        o.photon_map = 1;
+    } else if (photons) { // BuildCausticPhotonMap, Main.cpp:194
+        uint32_t stored = 0;
+        if (bhrt_photon_build(scene, &o, photons, &stored)) return fail("BuildCausticPhotonMap");
+        printf("caustic photon map: %u photons\n", stored);
+        o.photon_map = 1;
+    }
+    if (o.photon_map && !photon_out.empty() && bhrt_photon_export(scene, photon_out.c_str())) return fail("photon export");
     bhrt_stats st;
     if (bhrt_render(scene, &o, rgb.data(), rad.empty() ? nullptr : rad.data(), &st)) return fail("BeginRender");
     const double rays = (double)st.closest_rays + (double)st.shadow_rays;

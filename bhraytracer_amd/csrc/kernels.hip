@@ -1674,6 +1674,32 @@ int bhrt_math_eval_dev(int fn, const float *a, const float *b, size_t n, float *
     return BHRT_OK;
 }
 
+// D->h_photons (balanced, heap order, slot 0 unused) -> HBM: the 24-byte records, the decoded hot/cold copy the gather
+// walks (PhotonMapDev) and the bounds of the photon positions.
+static int InstallPhotonMap(DeviceState *D)
+{
+    const uint32_t n = (uint32_t)D->h_photons.size() - 1;
+    if (D->d_photons) { (void)hipFree(D->d_photons); D->d_photons = nullptr; D->n_photons = 0; }
+    HIP_CHECK(hipMalloc(&D->d_photons, ((size_t)n + 1) * sizeof(DPhoton)));
+    HIP_CHECK(hipMemcpy(D->d_photons, D->h_photons.data(), ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyHostToDevice));
+    D->n_photons = n;
+    if (D->d_ph_hot) (void)hipFree(D->d_ph_hot);
+    if (D->d_ph_cold) (void)hipFree(D->d_ph_cold);
+    D->d_ph_hot = nullptr; D->d_ph_cold = nullptr;
+    HIP_CHECK(hipMalloc(&D->d_ph_hot, ((size_t)n + 1) * sizeof(float4)));
+    HIP_CHECK(hipMalloc(&D->d_ph_cold, ((size_t)n + 1) * 2 * sizeof(float4)));
+    hipLaunchKernelGGL(k_photon_expand, dim3((n + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->d_photons, n, D->d_ph_hot, D->d_ph_cold);
+    HIP_CHECK(hipStreamSynchronize(D->stream));
+    D->pm.hot = D->d_ph_hot; D->pm.cold = D->d_ph_cold; D->pm.n = (int)n; D->pm.half = (int)n / 2 - 1;
+    for (int k = 0; k < 3; k++) { D->pm.lo[k] = BHRT_BIGFLOAT; D->pm.hi[k] = -BHRT_BIGFLOAT; }
+    for (size_t i = 1; i <= n; i++)
+        for (int k = 0; k < 3; k++) {
+            D->pm.lo[k] = std::min(D->pm.lo[k], D->h_photons[i].pos[k]);
+            D->pm.hi[k] = std::max(D->pm.hi[k], D->h_photons[i].pos[k]);
+        }
+    return BHRT_OK;
+}
+
 int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, uint32_t *n_stored)
 {
     int rc = EnsureUploaded(scene);
@@ -1738,26 +1764,11 @@ int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_pho
     D->h_photons.assign((size_t)n + 1, HostPhoton());
     HIP_CHECK(hipMemcpyAsync(D->h_photons.data(), d_out, ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyDeviceToHost, D->stream));
     HIP_CHECK(hipStreamSynchronize(D->stream));
+    (void)hipFree(d_out);
     memset(&D->h_photons[0], 0, sizeof(HostPhoton));
     BalancePhotons(D->h_photons);
-    HIP_CHECK(hipMemcpy(d_out, D->h_photons.data(), ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyHostToDevice));
-    D->d_photons = d_out;
-    D->n_photons = n;
-    // decoded copy for the gather (PhotonMapDev) + the bounds of the photon positions
-    if (D->d_ph_hot) (void)hipFree(D->d_ph_hot);
-    if (D->d_ph_cold) (void)hipFree(D->d_ph_cold);
-    D->d_ph_hot = nullptr; D->d_ph_cold = nullptr;
-    HIP_CHECK(hipMalloc(&D->d_ph_hot, ((size_t)n + 1) * sizeof(float4)));
-    HIP_CHECK(hipMalloc(&D->d_ph_cold, ((size_t)n + 1) * 2 * sizeof(float4)));
-    hipLaunchKernelGGL(k_photon_expand, dim3((n + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, d_out, n, D->d_ph_hot, D->d_ph_cold);
-    HIP_CHECK(hipStreamSynchronize(D->stream));
-    D->pm.hot = D->d_ph_hot; D->pm.cold = D->d_ph_cold; D->pm.n = (int)n; D->pm.half = (int)n / 2 - 1;
-    for (int k = 0; k < 3; k++) { D->pm.lo[k] = BHRT_BIGFLOAT; D->pm.hi[k] = -BHRT_BIGFLOAT; }
-    for (size_t i = 1; i <= n; i++)
-        for (int k = 0; k < 3; k++) {
-            D->pm.lo[k] = std::min(D->pm.lo[k], D->h_photons[i].pos[k]);
-            D->pm.hi[k] = std::max(D->pm.hi[k], D->h_photons[i].pos[k]);
-        }
+    rc = InstallPhotonMap(D);
+    if (rc) return rc;
     if (n_stored) *n_stored = n;
     return BHRT_OK;
 }
@@ -1810,6 +1821,32 @@ int bhrt_photon_export(const bhrt_scene *scene, const char *dat_path)
     fclose(fp);
     if (!ok) { SetError("short write"); return BHRT_ERR_IO; }
     return BHRT_OK;
+}
+
+int bhrt_photon_import(bhrt_scene *scene, const char *dat_path, int rebalance)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    if (!dat_path) { SetError("null path"); return BHRT_ERR_ARG; }
+    FILE *fp = fopen(dat_path, "rb");
+    if (!fp) { SetError(std::string("cannot open ") + dat_path); return BHRT_ERR_IO; }
+    fseek(fp, 0, SEEK_END);
+    const long bytes = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    if (bytes <= 0 || bytes % (long)sizeof(HostPhoton) != 0 || (size_t)bytes / sizeof(HostPhoton) > (1u << 28)) {
+        fclose(fp);
+        SetError("photon file: size is not a positive multiple of the 24-byte record");
+        return BHRT_ERR_IO;
+    }
+    const size_t n = (size_t)bytes / sizeof(HostPhoton);
+    DeviceState *D = scene->dev;
+    D->h_photons.assign(n + 1, HostPhoton());
+    const bool ok = fread(&D->h_photons[1], sizeof(HostPhoton), n, fp) == n;
+    fclose(fp);
+    if (!ok) { D->h_photons.clear(); SetError("photon file: short read"); return BHRT_ERR_IO; }
+    memset(&D->h_photons[0], 0, sizeof(HostPhoton));
+    if (rebalance) BalancePhotons(D->h_photons); // InitializePhotonMapByFile runs PrepareForIrradianceEstimation again (cyPhotonMap.h:409-417)
+    return InstallPhotonMap(D);
 }
 
 } // extern "C"

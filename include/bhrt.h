@@ -128,6 +128,10 @@ int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_pho
 int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *n, size_t cnt, float radius, float *irrad, float *dir);
 int bhrt_photon_get(const bhrt_scene *scene, void *photons_out /* 24 B records, balanced order */, uint32_t capacity, uint32_t *n);
 int bhrt_photon_export(const bhrt_scene *scene, const char *dat_path); /* 24-byte records, Main.cpp:383-385 */
+/* Loads a map written by bhrt_photon_export or by the reference (Resource/causticPhotonMap.dat) instead of building it.
+ * rebalance = 1: PhotonMap::InitializePhotonMapByFile (cyPhotonMap.h:409-417), which balances the records again;
+ * rebalance = 0: the records are used in the order of the file (a balanced map as exported: the cached photon pass). */
+int bhrt_photon_import(bhrt_scene *scene, const char *dat_path, int rebalance);
 
 /* ---- test hook: csrc/bhrt_detmath.h evaluated on the device, to prove host and device produce the same bits.
  * fn: 0 sin 1 cos 2 tan 3 acos 4 asin 5 atan2(a,b) 6 pow(a,b) 7 rand_to_unit(bits of a) 8 a/b 9 sqrt(a); host pointers */

@@ -123,3 +123,20 @@ def test_gpu_photon_map_vs_oracle(B, load_scene, O):
     path = os.path.join(tempfile.mkdtemp(), "causticPhotonMap.dat")
     sc.photon_export(path)
     assert np.array_equal(np.fromfile(path, np.uint8).reshape(-1, 24), bal)
+    # import: as is (the cached photon pass) and through InitializePhotonMapByFile, which balances the records again
+    # (cyPhotonMap.h:409-417)
+    ref_i, ref_d = sc.photon_gather(p, nr, 0.5)
+    sc2 = load_scene("c5_caustics")
+    sc2.photon_import(path)
+    assert np.array_equal(sc2.photon_get(), bal)
+    gi2, gd2 = sc2.photon_gather(p, nr, 0.5)
+    assert same_bits(gi2, ref_i) and same_bits(gd2, ref_d)
+    sc2.photon_import(path, rebalance=True)
+    rebal = O.photon_balance(bal)
+    assert np.array_equal(sc2.photon_get(), rebal)
+    O.photon_attach(rebal)
+    oi3, od3 = O.photon_gather(p, nr, 0.5)
+    gi3, gd3 = sc2.photon_gather(p, nr, 0.5)
+    assert same_bits(gi3, oi3) and same_bits(gd3, od3)
+    with pytest.raises(B.BhrtError):
+        sc2.photon_import(path + ".missing")
