@@ -39,6 +39,50 @@ def test_scene_dump_matches_front_end(B, tmp_path):
     assert lf[-1] == np.float32(fv.header.all_light_intensity)
 
 
+def _shipped_xmls():
+    import glob
+    return sorted(os.path.relpath(f, REFERENCE) for f in glob.glob(os.path.join(REFERENCE, "Resource", "**", "*.xml"), recursive=True))
+
+
+@pytest.mark.parametrize("rel", _shipped_xmls() if os.path.isdir(REFERENCE) else [])
+def test_front_end_dump_of_every_shipped_scene(rel, B, tmp_path):
+    """xmlload's result on all 19 shipped XMLs (scene graph, transforms, camera frame, sorted lights,
+    materials) equals the front-end's flat scene bit for bit.  Meshes are absent from the reference checkout, so their
+    nodes are null objects on both sides."""
+    pre = str(tmp_path / "d")
+    run_ref(rel, pre, "dump", cwd=REFERENCE)
+    cwd = os.getcwd()
+    os.chdir(REFERENCE)
+    try:
+        fv = B.Scene(rel).flat_view()
+    finally:
+        os.chdir(cwd)
+    u32 = lambda a: np.asarray(a, np.float32).view(np.uint32)
+    nf = np.fromfile(pre + ".nodes_f32", np.uint32).reshape(-1, 21)
+    assert np.array_equal(nf, u32([list(n.xf.tm) + list(n.xf.pos) + list(n.xf.itm) for n in fv.nodes]).reshape(-1, 21))
+    ni = np.fromfile(pre + ".nodes_i32", np.int32).reshape(-1, 5)
+    assert np.array_equal(ni, np.array([[n.parent, n.depth, n.obj_type, n.mesh, n.material] for n in fv.nodes], np.int32).reshape(-1, 5))
+    c = fv.header.camera
+    cam = list(c.pos) + list(c.dir) + list(c.up) + [c.fov, c.focaldist, c.width, c.height] + list(c.top_left) + list(c.dd_x) + list(c.dd_y)
+    assert np.array_equal(np.fromfile(pre + ".camera_f32", np.uint32), u32(cam))
+    lights = []
+    for l in fv.lights:
+        lights += [l.type] + list(l.intensity) + (list(l.vec) if l.type else [0, 0, 0]) + [l.size if l.type == 2 else 0]
+    lights.append(fv.header.all_light_intensity)
+    assert np.array_equal(np.fromfile(pre + ".lights_f32", np.uint32), u32(lights))
+    mf = np.fromfile(pre + ".materials_f32", np.float32).reshape(-1, 26)
+    assert len(mf) == len(fv.materials)
+    for row, m in zip(mf, fv.materials):
+        if m.kind != 0:
+            assert (row == -1).all()            # MultiMtl
+            continue
+        mine = []
+        for tc in (m.diffuse, m.specular, m.refraction):
+            mine += list(tc.color) + [1.0 if tc.map >= 0 else 0.0]
+        assert np.array_equal(u32(row[:12]), u32(mine))   # row[12:20]: reflection / emission, parsed but never used by Shade (Q8)
+        assert np.array_equal(u32(row[20:]), u32([m.glossiness] + list(m.absorption) + [m.ior, m.refraction_glossiness]))
+
+
 SHIPPED = ["proj12_backfaceTest", "proj3", "proj13", "proj7", "proj10", "proj2"]
 
 
