@@ -71,8 +71,10 @@ __device__ inline bool pixel_of(const PassInfo &P, uint32_t q, int &i, int &j)
 // ONE atomic per workgroup and queue.  (One atomic per wave was the bottleneck of the first version: a
 // single word takes ~88 atomics/us on MI355X, and a 16 M-lane launch has 262 k waves.)
 // All threads of the block must call it (convergent call sites only).  kShadeBlock threads per block.
+// 512 threads: two workgroups fit a CU at k_shade's 126 VGPRs, so one's load / barrier / store phases overlap the
+// other's arithmetic (1024 = the whole CU in lockstep: +18 % kernel time); 256 is no faster and doubles the queue atomics.
 #ifndef BHRT_SHADE_BLOCK
-#define BHRT_SHADE_BLOCK 1024
+#define BHRT_SHADE_BLOCK 512
 #endif
 constexpr int kShadeBlock = BHRT_SHADE_BLOCK;
 constexpr int kShadeWaves = kShadeBlock / 64;
@@ -508,8 +510,11 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
     F.info[f] = (F.info[f] & 7u) | (dmode << 3) | (light_idx << 8) | (flags << 16) | ((uint32_t)(mi & 0xfff) << 20);
 }
 
+#ifndef BHRT_SHADE_WAVES
+#define BHRT_SHADE_WAVES 4 /* waves per SIMD the register allocation must allow */
+#endif
 template <bool kCamera>
-__global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene S, RenderParams R, PassInfo P, RayQueue qin, HitBuf hb, uint32_t n, RayQueue qout,
+__global__ void __launch_bounds__(kShadeBlock, BHRT_SHADE_WAVES) k_shade(DevScene S, RenderParams R, PassInfo P, RayQueue qin, HitBuf hb, uint32_t n, RayQueue qout,
                                                    ShadowQueue qs, Frames F, float *samples, Counters *cnt, RayOrder ord)
 {
     __shared__ BlockAllocLds lds;
