@@ -297,9 +297,12 @@ __global__ void __launch_bounds__(kBlock) k_trace_mesh(DevScene S, PassInfo P, R
 }
 
 // frame == nullptr: visibility goes to vis[i] (public bhrt_trace_shadow_*), else to vis[frame[i]]
-__global__ void __launch_bounds__(kBlock) k_trace_shadow(DevScene S, ShadowQueue q, uint32_t n, float *vis)
+// n_dev != nullptr: the queue length is read on the device (launched ahead of the host's copy of the counters with a
+// grid sized for the upper bound n)
+__global__ void __launch_bounds__(kBlock) k_trace_shadow(DevScene S, ShadowQueue q, uint32_t n, const uint32_t *n_dev, float *vis)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
     if (i >= n) return;
     const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]), d = v3(q.dx[i], q.dy[i], q.dz[i]);
     const float v = trace_shadow(S, o, d, q.tmax[i]);
@@ -307,9 +310,11 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow(DevScene S, ShadowQueue
 }
 // Scenes with meshes, render path: spheres and planes here; a ray they leave unoccluded that enters a mesh's root box
 // is parked on list RC_MESH and decided by k_shadow_mesh in dense workgroups (same reason as k_trace_mesh).
-__global__ void __launch_bounds__(kBlock) k_trace_shadow_park(DevScene S, ShadowQueue q, uint32_t n, float *vis, RayOrder ord, Counters *cnt)
+__global__ void __launch_bounds__(kBlock) k_trace_shadow_park(DevScene S, ShadowQueue q, uint32_t n, const uint32_t *n_dev, float *vis, RayOrder ord, Counters *cnt)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
+    if (blockIdx.x * blockDim.x >= n) return; // uniform per workgroup
     float v = 1.f;
     if (i < n) {
         v = trace_shadow_t<1>(S, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), q.tmax[i]);
@@ -1057,7 +1062,8 @@ struct DeviceState {
     struct PendingTimer { int e0, e1; double *acc; };
     std::vector<hipEvent_t> ev_pool;
     std::vector<PendingTimer> ev_pending;
-    int ev_used = 0;
+    std::vector<int> ev_free;                  // pool indices not in use
+    hipEvent_t ev_counts = nullptr;            // "the step's counters have reached the host"
     // caustic photon map (balanced, heap order, slot 0 unused) + gather scratch
     DPhoton *d_photons = nullptr;
     uint32_t n_photons = 0;
@@ -1093,6 +1099,7 @@ void DestroyDeviceState(DeviceState *d)
     if (d->h_cnt) (void)hipHostFree(d->h_cnt);
     for (int k = 0; k < 2; k++) if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
     for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
+    if (d->ev_counts) (void)hipEventDestroy(d->ev_counts);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -1191,8 +1198,9 @@ struct Timer {
     int e0;
     static hipEvent_t Get(DeviceState *d, int &idx)
     {
-        if (d->ev_used == (int)d->ev_pool.size()) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); d->ev_pool.push_back(e); }
-        idx = d->ev_used++;
+        if (d->ev_free.empty()) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); d->ev_pool.push_back(e); d->ev_free.push_back((int)d->ev_pool.size() - 1); }
+        idx = d->ev_free.back();
+        d->ev_free.pop_back();
         return d->ev_pool[idx];
     }
     Timer(DeviceState *d, double *a) : D(d), acc(a) { (void)hipEventRecord(Get(D, e0), D->stream); }
@@ -1203,14 +1211,20 @@ struct Timer {
         D->ev_pending.push_back({e0, e1, acc});
     }
 };
-static void FlushTimers(DeviceState *D) // call after the stream has been synchronised
+// Reads back the timers whose kernels have finished; the others (kernels launched ahead of the host, e.g. the shadow
+// trace of the current step) stay pending until a later call.  final = true: after a full stream synchronisation.
+static void FlushTimers(DeviceState *D, bool final = false)
 {
-    for (auto &p : D->ev_pending) {
+    size_t keep = 0;
+    for (size_t k = 0; k < D->ev_pending.size(); k++) {
+        const auto p = D->ev_pending[k];
+        if (!final && hipEventQuery(D->ev_pool[p.e1]) != hipSuccess) { D->ev_pending[keep++] = p; continue; }
         float ms = 0;
         if (p.acc && hipEventElapsedTime(&ms, D->ev_pool[p.e0], D->ev_pool[p.e1]) == hipSuccess) *p.acc += ms * 1e-3;
+        D->ev_free.push_back(p.e0);
+        D->ev_free.push_back(p.e1);
     }
-    D->ev_pending.clear();
-    D->ev_used = 0;
+    D->ev_pending.resize(keep);
 }
 
 static int EnsurePhotonScratch(DeviceState *D, uint32_t lanes)
@@ -1387,7 +1401,20 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 t.Stop();
             }
             HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, BHRT_COUNTERS_HOST_BYTES, hipMemcpyDeviceToHost, D->stream)); // n_next, n_shadow, n_frames, overflow
-            HIP_CHECK(hipStreamSynchronize(D->stream));
+            HIP_CHECK(hipEventRecord(D->ev_counts, D->stream));
+            { // the shadow trace of this step goes out before the host has the counters: its grid covers the upper bound
+              // (<= 1 shadow ray per shaded ray, <= the queue's capacity) and the kernels read the length on the device
+                Timer t(D, &st->seconds_trace_shadow);
+                const uint32_t bound = std::min<uint32_t>(n_cur, R.cap_shadow);
+                const dim3 hg((bound + kBlock - 1) / kBlock), hb(kBlock);
+                if (H->n_meshes > 0) {
+                    hipLaunchKernelGGL(k_trace_shadow_park, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis, RO, D->d_cnt);
+                    hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
+                    hipLaunchKernelGGL(k_shadow_mesh, dim3(hg.x + BHRT_ORDER_SHARDS), hb, 0, D->stream, D->S, SQ, F.vis, RO);
+                } else hipLaunchKernelGGL(k_trace_shadow, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis);
+                t.Stop();
+            }
+            HIP_CHECK(hipEventSynchronize(D->ev_counts));
             FlushTimers(D);
             if (D->h_cnt->overflow.v) { overflow = true; break; }
             if (first_step) { // camera step: dead rays of edge tiles are not rays
@@ -1397,17 +1424,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 first_step = false;
             } else pass_closest += n_cur;
             const uint32_t n_sh = D->h_cnt->n_shadow.v;
-            if (n_sh) {
-                Timer t(D, &st->seconds_trace_shadow);
-                const dim3 hg((n_sh + kBlock - 1) / kBlock), hb(kBlock);
-                if (H->n_meshes > 0) {
-                    hipLaunchKernelGGL(k_trace_shadow_park, hg, hb, 0, D->stream, D->S, SQ, n_sh, F.vis, RO, D->d_cnt);
-                    hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
-                    hipLaunchKernelGGL(k_shadow_mesh, dim3(hg.x + BHRT_ORDER_SHARDS), hb, 0, D->stream, D->S, SQ, F.vis, RO);
-                } else hipLaunchKernelGGL(k_trace_shadow, hg, hb, 0, D->stream, D->S, SQ, n_sh, F.vis);
-                t.Stop();
-                st->shadow_rays += n_sh; st->launches_trace_shadow++;
-            }
+            if (n_sh) { st->shadow_rays += n_sh; st->launches_trace_shadow++; }
             if (o.photon_map && D->h_cnt->n_frames.v > frame_marks.back()) { // caustic term of the frames opened in this step
                 Timer t(D, &st->reserved[0]);
                 const GatherToFrames sink = {F, D->S.materials};
@@ -1445,7 +1462,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         q += npx;
     }
     HIP_CHECK(hipStreamSynchronize(D->stream));
-    FlushTimers(D);
+    FlushTimers(D, true);
     st->seconds_total += std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
     return BHRT_OK;
 }
@@ -1498,6 +1515,7 @@ int bhrt_scene_upload(bhrt_scene *scene, int device)
     HIP_CHECK(hipMalloc(&D->d_cnt, sizeof(Counters)));
     HIP_CHECK(hipMalloc(&D->d_seg, (8 * BHRT_ORDER_SHARDS + 3) * sizeof(uint32_t)));
     HIP_CHECK(hipHostMalloc(&D->h_cnt, sizeof(Counters)));
+    HIP_CHECK(hipEventCreateWithFlags(&D->ev_counts, hipEventDisableTiming));
     DevScene &S = D->S;
     S.blob = D->d_blob;
     S.nodes = (const bhrt_node *)(D->d_blob + H->off_nodes);
@@ -1583,7 +1601,7 @@ int bhrt_trace_shadow_dev(bhrt_scene *scene, const float *d_rays_soa, const floa
     q.ox = f; q.oy = f + n; q.oz = f + 2 * n; q.dx = f + 3 * n; q.dy = f + 4 * n; q.dz = f + 5 * n;
     q.tmax = const_cast<float *>(d_tmax); q.frame = nullptr;
     hipStream_t s = stream ? (hipStream_t)stream : scene->dev->stream;
-    hipLaunchKernelGGL(k_trace_shadow, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, q, (uint32_t)n, d_vis);
+    hipLaunchKernelGGL(k_trace_shadow, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, q, (uint32_t)n, (const uint32_t *)nullptr, d_vis);
     HIP_CHECK(hipGetLastError());
     if (!stream) HIP_CHECK(hipStreamSynchronize(s));
     return BHRT_OK;
