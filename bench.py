@@ -160,15 +160,13 @@ def main():
     d_rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
     d_rad = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
 
+    gather_scratch = {}
+
     def step():
         st = sc.render_dev(opts, d_rgb.data_ptr(), d_rad.data_ptr())
         if N > 1:
-            if args.rehearse_on_one_gpu:
-                BD.gather_framebuffer(d_rad.cpu(), tile, rank, N)
-                BD.gather_framebuffer(d_rgb.cpu(), tile, rank, N)
-            else:
-                BD.gather_framebuffer(d_rad, tile, rank, N)  # RCCL all_gather of the float radiance tiles
-                BD.gather_framebuffer(d_rgb, tile, rank, N)  # and of the RGB8 tiles
+            # pack -> ONE all_gather of byte blocks (RCCL; through the host with gloo when rehearsing on one GPU) -> unpack
+            BD.gather_frame_dev(d_rgb, d_rad, tile, rank, N, scratch=gather_scratch, via_host=args.rehearse_on_one_gpu)
         return st
 
     def sync():
@@ -236,7 +234,7 @@ def main():
             "config": {"workload": f"{os.path.basename(scene_rel)} {W}x{H}, {spp} spp ({spp1} per GPU), GI depth {gi}, "
                                    f"internal bounces 16, keyed RNG seed 0, {tile}x{tile} interleaved tiles over {N} GPU(s)",
                        "rays_per_frame": rays_total / args.steps, "camera_samples_per_frame": samples_total / args.steps,
-                       "framebuffer_gather": "rccl all_gather (float radiance + rgb8 tiles)" if N > 1 else "none"},
+                       "framebuffer_gather": "one rccl all_gather of packed tiles (float radiance + rgb8), native pack/unpack kernels" if N > 1 else "none"},
             "photon_build_s": photon_build_s, "photon_gather_s_per_frame": (agg.get("reserved0", 0.0) / args.steps) if photon_build_s else None,
             "photon_heap_pass_s_per_frame": (agg.get("reserved1", 0.0) / args.steps) if photon_build_s else None,
             "photon_heap_queries_per_frame": (agg.get("reserved2", 0.0) / args.steps) if photon_build_s else None,

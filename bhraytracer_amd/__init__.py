@@ -65,6 +65,7 @@ EXPORTS = [
     "bhrt_trace_closest_host", "bhrt_trace_closest_dev", "bhrt_trace_shadow_host", "bhrt_trace_shadow_dev",
     "bhrt_render", "bhrt_render_dev", "bhrt_render_samples", "bhrt_photon_build", "bhrt_photon_gather_host",
     "bhrt_photon_get", "bhrt_photon_export", "bhrt_photon_import", "bhrt_save_png", "bhrt_math_eval_dev",
+    "bhrt_tiles_block_bytes", "bhrt_tiles_pack_dev", "bhrt_tiles_unpack_dev",
 ]
 
 
@@ -75,6 +76,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise BhrtError(f"{LIB_PATH} not found: build it with `python -m bhraytracer_amd.build` "
                             "(the render path has no fallback)")
+        # torch ships its own libamdhip64 under the SONAME of the system's: whichever copy a process loads first serves
+        # both.  Two HIP runtimes in one process do not both see the GPU, so when torch is present (tests, bench.py:
+        # device tensors, torch.distributed) it goes first.  The library itself does not depend on torch.
+        import sys
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         L.bhrt_last_error.restype = C.c_char_p
         L.bhrt_scene_free.restype = None
@@ -239,6 +249,22 @@ def math_eval_dev(fn: int, a, b=None):
     out = np.empty_like(a)
     _check(lib().bhrt_math_eval_dev(int(fn), _ptr(a), _ptr(bb) if bb is not None else None, C.c_size_t(a.size), _ptr(out)))
     return out
+
+
+def tiles_block_bytes(width: int, height: int, tile: int, world: int) -> int:
+    f = lib().bhrt_tiles_block_bytes
+    f.restype = C.c_size_t
+    return int(f(width, height, tile, world))
+
+
+def tiles_pack_dev(rgb8_ptr: int, radiance_ptr: int, width, height, tile, rank, world, block_ptr: int, stream: int = 0):
+    _check(lib().bhrt_tiles_pack_dev(C.c_void_p(rgb8_ptr), C.c_void_p(radiance_ptr), width, height, tile, rank, world, C.c_void_p(block_ptr),
+                                     C.c_void_p(stream)))
+
+
+def tiles_unpack_dev(blocks_ptr: int, width, height, tile, world, rgb8_ptr: int, radiance_ptr: int, stream: int = 0):
+    _check(lib().bhrt_tiles_unpack_dev(C.c_void_p(blocks_ptr), width, height, tile, world, C.c_void_p(rgb8_ptr), C.c_void_p(radiance_ptr),
+                                       C.c_void_p(stream)))
 
 
 def save_png(path: str, rgb8: np.ndarray):

@@ -1031,6 +1031,55 @@ __global__ void __launch_bounds__(kBlock) k_photon_gather_heap(Sink sink, const 
     sink.done(q, found, irr, d);
 }
 
+// ------------------------------------------------------------------------------------------------
+// multi-GPU framebuffer exchange: tile t (row-major, tile x tile pixels) belongs to rank t mod world.
+// A rank's block of the exchange buffer = its tiles_per_rank tiles, float radiance section first (12 B / pixel), RGB8
+// section behind it (3 B / pixel); tile k of rank r is tile k * world + r; pixels outside the image are zero.
+__device__ inline bool tile_pixel(uint32_t p, int W, int H, int tile, int tiles_x, int world, int rank, int &i, int &j, bool &exists)
+{
+    const uint32_t tp = (uint32_t)(tile * tile);
+    const uint32_t k = p / tp, within = p % tp;
+    const uint32_t t = k * (uint32_t)world + (uint32_t)rank;
+    const int tiles_y = (H + tile - 1) / tile;
+    exists = t < (uint32_t)(tiles_x * tiles_y);
+    i = (int)(t % (uint32_t)tiles_x) * tile + (int)(within % (uint32_t)tile);
+    j = (int)(t / (uint32_t)tiles_x) * tile + (int)(within / (uint32_t)tile);
+    return exists && i < W && j < H;
+}
+__global__ void __launch_bounds__(kBlock) k_tiles_pack(const uint8_t *rgb8, const float *radiance, int W, int H, int tile, int tiles_x, int rank, int world,
+                                                        uint32_t px_per_rank, float *out_rad, uint8_t *out_rgb)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= px_per_rank) return;
+    int i, j;
+    bool exists;
+    const bool in = tile_pixel(p, W, H, tile, tiles_x, world, rank, i, j, exists);
+    const size_t pix = (size_t)j * W + i;
+    for (int c = 0; c < 3; c++) {
+        out_rad[(size_t)p * 3 + c] = in ? radiance[pix * 3 + c] : 0.f;
+        out_rgb[(size_t)p * 3 + c] = in ? rgb8[pix * 3 + c] : (uint8_t)0;
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_tiles_unpack(const uint8_t *gathered, size_t block_bytes, int W, int H, int tile, int tiles_x, int world, uint32_t px_per_rank,
+                                                          uint8_t *rgb8, float *radiance)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; // (rank, pixel of the rank's block)
+    if (g >= px_per_rank * (uint32_t)world) return;
+    const int rank = (int)(g / px_per_rank);
+    const uint32_t p = g % px_per_rank;
+    int i, j;
+    bool exists;
+    if (!tile_pixel(p, W, H, tile, tiles_x, world, rank, i, j, exists)) return;
+    const uint8_t *blk = gathered + (size_t)rank * block_bytes;
+    const float *rad = (const float *)blk;
+    const uint8_t *rgb = blk + (size_t)px_per_rank * 12;
+    const size_t pix = (size_t)j * W + i;
+    for (int c = 0; c < 3; c++) {
+        radiance[pix * 3 + c] = rad[(size_t)p * 3 + c];
+        rgb8[pix * 3 + c] = rgb[(size_t)p * 3 + c];
+    }
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -1680,6 +1729,46 @@ int bhrt_render_samples(bhrt_scene *scene, const bhrt_opts *opts, int x0, int y0
 }
 
 // ---- caustic photon map --------------------------------------------------------------------------
+static bool TileArgsOk(int W, int H, int tile, int rank, int world)
+{
+    if (W <= 0 || H <= 0 || tile <= 0 || world <= 0 || rank < 0 || rank >= world) { SetError("bad tile partition"); return false; }
+    return true;
+}
+size_t bhrt_tiles_block_bytes(int width, int height, int tile, int world)
+{
+    if (width <= 0 || height <= 0 || tile <= 0 || world <= 0) return 0;
+    const size_t n_tiles = (size_t)((width + tile - 1) / tile) * (size_t)((height + tile - 1) / tile);
+    const size_t per_rank = (n_tiles + (size_t)world - 1) / (size_t)world;
+    return (per_rank * (size_t)tile * tile * 15 + 15) & ~(size_t)15; // blocks stay 16-byte aligned in the gathered buffer
+}
+static uint32_t TilesPixelsPerRank(int width, int height, int tile, int world)
+{
+    const size_t n_tiles = (size_t)((width + tile - 1) / tile) * (size_t)((height + tile - 1) / tile);
+    return (uint32_t)(((n_tiles + (size_t)world - 1) / (size_t)world) * (size_t)tile * tile);
+}
+int bhrt_tiles_pack_dev(const uint8_t *d_rgb8, const float *d_radiance, int width, int height, int tile, int rank, int world, void *d_block, void *stream)
+{
+    if (!TileArgsOk(width, height, tile, rank, world)) return BHRT_ERR_ARG;
+    if (!d_rgb8 || !d_radiance || !d_block) { SetError("null buffer"); return BHRT_ERR_ARG; }
+    const uint32_t px = TilesPixelsPerRank(width, height, tile, world);
+    hipLaunchKernelGGL(k_tiles_pack, dim3((px + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, d_rgb8, d_radiance, width, height, tile,
+                       (width + tile - 1) / tile, rank, world, px, (float *)d_block, (uint8_t *)d_block + (size_t)px * 12);
+    HIP_CHECK(hipGetLastError());
+    return BHRT_OK;
+}
+int bhrt_tiles_unpack_dev(const void *d_blocks, int width, int height, int tile, int world, uint8_t *d_rgb8, float *d_radiance, void *stream)
+{
+    if (!TileArgsOk(width, height, tile, 0, world)) return BHRT_ERR_ARG;
+    if (!d_rgb8 || !d_radiance || !d_blocks) { SetError("null buffer"); return BHRT_ERR_ARG; }
+    const size_t bb = bhrt_tiles_block_bytes(width, height, tile, world);
+    const uint32_t px = TilesPixelsPerRank(width, height, tile, world);
+    const uint64_t total = (uint64_t)px * (uint64_t)world;
+    hipLaunchKernelGGL(k_tiles_unpack, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, (hipStream_t)stream, (const uint8_t *)d_blocks, bb, width,
+                       height, tile, (width + tile - 1) / tile, world, px, d_rgb8, d_radiance);
+    HIP_CHECK(hipGetLastError());
+    return BHRT_OK;
+}
+
 int bhrt_math_eval_dev(int fn, const float *a, const float *b, size_t n, float *out)
 {
     int count = 0;

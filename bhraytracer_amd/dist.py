@@ -48,6 +48,34 @@ def unpack_tiles(allb: torch.Tensor, width: int, height: int, tile: int) -> torc
     return img[:height, :width]
 
 
+def gather_frame_dev(rgb8: torch.Tensor, radiance: torch.Tensor, tile: int, rank: int, world: int, group=None, scratch=None, via_host=False):
+    """GPU path of the exchange: native pack (bhrt_tiles_pack_dev) -> ONE all_gather of byte blocks -> native unpack
+    into the same (H, W, 3) uint8 / float32 device tensors, in place.  `scratch`: dict reused across frames.
+    via_host: move the blocks through host memory and a CPU backend (rehearsal of N ranks on one GPU, where RCCL
+    cannot run); pack and unpack still run on the device."""
+    import torch.distributed as dist
+    import bhraytracer_amd as B
+    if world == 1:
+        return
+    H, W, _ = rgb8.shape
+    bb = B.tiles_block_bytes(W, H, tile, world)
+    scratch = scratch if scratch is not None else {}
+    if scratch.get("bytes") != (bb, world):
+        scratch["mine"] = torch.empty(bb, dtype=torch.uint8, device=rgb8.device)
+        scratch["all"] = torch.empty(bb * world, dtype=torch.uint8, device=rgb8.device)
+        scratch["bytes"] = (bb, world)
+    stream = torch.cuda.current_stream().cuda_stream
+    B.tiles_pack_dev(rgb8.data_ptr(), radiance.data_ptr(), W, H, tile, rank, world, scratch["mine"].data_ptr(), stream)
+    if via_host:
+        torch.cuda.current_stream().synchronize()
+        all_cpu = torch.empty(bb * world, dtype=torch.uint8)
+        dist.all_gather_into_tensor(all_cpu, scratch["mine"].cpu(), group=group)
+        scratch["all"].copy_(all_cpu)
+    else:
+        dist.all_gather_into_tensor(scratch["all"], scratch["mine"], group=group)  # RCCL over xGMI
+    B.tiles_unpack_dev(scratch["all"].data_ptr(), W, H, tile, world, rgb8.data_ptr(), radiance.data_ptr(), stream)
+
+
 def gather_framebuffer(img: torch.Tensor, tile: int, rank: int, world: int, group=None) -> torch.Tensor:
     """All ranks end up with the complete image. One all_gather, (W*H*C*itemsize)/world bytes per rank."""
     import torch.distributed as dist

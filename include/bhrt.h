@@ -133,6 +133,16 @@ int bhrt_photon_export(const bhrt_scene *scene, const char *dat_path); /* 24-byt
  * rebalance = 0: the records are used in the order of the file (a balanced map as exported: the cached photon pass). */
 int bhrt_photon_import(bhrt_scene *scene, const char *dat_path, int rebalance);
 
+/* ---- multi-GPU framebuffer exchange (no counterpart in the single-process reference) ------------------
+ * Tile t (row-major over ceil(W/tile) x ceil(H/tile) tiles) belongs to rank t mod world, the same rule bhrt_render*
+ * applies through bhrt_opts.rank / world_size / tile_size.  A rank packs the tiles it rendered into ONE block
+ * (float radiance section, then RGB8 section); one all-gather of the blocks (RCCL) and one unpack give every rank
+ * the whole image.  Device pointers; `stream` is a hipStream_t (NULL = the default stream), the calls do not synchronise. */
+size_t bhrt_tiles_block_bytes(int width, int height, int tile, int world); /* bytes of one rank's block */
+int bhrt_tiles_pack_dev(const uint8_t *d_rgb8, const float *d_radiance, int width, int height, int tile, int rank, int world, void *d_block, void *stream);
+int bhrt_tiles_unpack_dev(const void *d_blocks /* world blocks, rank-major */, int width, int height, int tile, int world, uint8_t *d_rgb8, float *d_radiance,
+                          void *stream);
+
 /* ---- test hook: csrc/bhrt_detmath.h evaluated on the device, to prove host and device produce the same bits.
  * fn: 0 sin 1 cos 2 tan 3 acos 4 asin 5 atan2(a,b) 6 pow(a,b) 7 rand_to_unit(bits of a) 8 a/b 9 sqrt(a); host pointers */
 int bhrt_math_eval_dev(int fn, const float *a, const float *b, size_t n, float *out);
