@@ -355,9 +355,10 @@ __global__ void __launch_bounds__(64) k_mesh_prefix(Counters *cnt, RayOrder ord)
 // for the next trace, queue counters for the k_shade that follows), which saves a memset per step.
 __global__ void __launch_bounds__(128) k_order_prefix(Counters *cnt, RayOrder ord)
 {
-    // 96 segments (class-major), one lane each: read + reset its counter, then an exclusive scan of the segments' workgroup counts
+    // 96 segments (class-major), one lane each: read + reset its counter, then exclusive scans of the segments' workgroup
+    // counts and (heavy class) element counts
     constexpr uint32_t kSegs = 3 * BHRT_ORDER_SHARDS;
-    __shared__ uint32_t s_blocks[128];
+    __shared__ uint32_t s_blocks[128], s_frames[128];
     const uint32_t s = threadIdx.x;
     uint32_t c = 0;
     if (s < kSegs) {
@@ -366,17 +367,28 @@ __global__ void __launch_bounds__(128) k_order_prefix(Counters *cnt, RayOrder or
         if (c > ord.shard_cap) c = ord.shard_cap; // the writer flagged the overflow; never index past the segment
     }
     if (s == 0) { cnt->n_next.v = 0; cnt->n_shadow.v = 0; }
-    s_blocks[s] = (c + kShadeBlock - 1) / kShadeBlock;
+    const uint32_t blocks = (c + kShadeBlock - 1) / kShadeBlock;
+    const uint32_t frames = s < BHRT_ORDER_SHARDS ? c : 0u; // every ray of the heavy class opens exactly one Shade() frame
+    s_blocks[s] = blocks;
+    s_frames[s] = frames;
     __syncthreads();
-    for (uint32_t off = 1; off < 128; off <<= 1) { // Hillis-Steele inclusive scan
-        const uint32_t add = s >= off ? s_blocks[s - off] : 0u;
+    for (uint32_t off = 1; off < 128; off <<= 1) { // Hillis-Steele inclusive scans
+        const uint32_t add = s >= off ? s_blocks[s - off] : 0u, addf = s >= off ? s_frames[s - off] : 0u;
         __syncthreads();
         s_blocks[s] += add;
+        s_frames[s] += addf;
         __syncthreads();
     }
-    const uint32_t incl = s_blocks[s], excl = incl - (c + kShadeBlock - 1) / kShadeBlock;
-    if (s < kSegs) { ord.seg_start[s] = excl; ord.seg_count[s] = c; }
-    if (s == kSegs - 1) ord.seg_start[kSegs] = incl;
+    const uint32_t incl = s_blocks[s], excl = incl - blocks;
+    // Frame numbers without atomics: the heavy rays of segment s get frames [n_frames + (heavy rays before s), ...) in the
+    // order of the segment's list; k_shade adds the ray's position in the list.
+    const uint32_t base = cnt->n_frames.v;
+    if (s < kSegs) { ord.seg_start[s] = excl; ord.seg_count[s] = c; ord.frame_base[s] = base + s_frames[s] - frames; }
+    __syncthreads(); // every lane has read n_frames
+    if (s == kSegs - 1) {
+        ord.seg_start[kSegs] = incl;
+        cnt->n_frames.v = base + s_frames[s]; // the host's frame marks; may exceed the capacity: k_shade flags that as overflow
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -565,8 +577,9 @@ __global__ void __launch_bounds__(kShadeBlock, BHRT_SHADE_WAVES) k_shade(DevScen
         else if (kind == RK_REFR_IN) new_frame = hit.front != 0;      // MtlBlinn.cpp:507-510
         else new_frame = true;                                        // RK_REFR_OUT, MtlBlinn.cpp:527-533
     }
-    uint32_t f, u0, u1, u2;
-    block_alloc3(lds, &cnt->n_frames.v, new_frame ? 1u : 0u, 0u, nullptr, 0u, nullptr, 0u, f, u0, u1, u2);
+    // frame number = the segment's first frame (k_order_prefix) + the ray's place in the heavy list: no atomic, no barrier.
+    // new_frame holds for every ray of a heavy segment and for no other (k_trace_closest files rays with this predicate).
+    uint32_t f = ord.frame_base[seg] + local, u2;
     if (new_frame && f >= R.cap_frames) { atomicOr(&cnt->overflow.v, 1u); new_frame = false; }
 
     ShadeOut so;
@@ -1102,7 +1115,7 @@ struct DeviceState {
     float *d_samples = nullptr;                // 3 * cap_samples
     uint32_t *d_order = nullptr;               // 4 * BHRT_ORDER_SHARDS * order_shard_cap (shading order, device_types.h::RayOrder)
     uint32_t order_shard_cap = 0;
-    uint32_t *d_seg = nullptr;                 // seg_start[97] + seg_count[96] + mesh_start[33] + mesh_count[33]
+    uint32_t *d_seg = nullptr;                 // seg_start[97] + seg_count[96] + mesh_start[33] + mesh_count[33] + frame_base[96]
     uint32_t *d_park = nullptr;                // park_key[cap_rays] + park_sorted[cap_rays] + buckets + tile sums (RayOrder)
     Counters *d_cnt = nullptr;
     Counters *h_cnt = nullptr; // pinned
@@ -1408,7 +1421,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         ShadowQueue SQ; { float *p = D->d_shf; const size_t c = D->cap_rays; SQ.ox = p; SQ.oy = p + c; SQ.oz = p + 2 * c; SQ.dx = p + 3 * c; SQ.dy = p + 4 * c; SQ.dz = p + 5 * c; SQ.tmax = p + 6 * c; SQ.frame = D->d_shu; }
         Frames F = MakeFrames(D);
         RayOrder RO = {D->d_order, D->order_shard_cap, D->d_seg, D->d_seg + 3 * BHRT_ORDER_SHARDS + 1, D->d_seg + 6 * BHRT_ORDER_SHARDS + 1, D->d_seg + 7 * BHRT_ORDER_SHARDS + 2,
-                       D->d_park, D->d_park + D->cap_rays, D->d_park + 2 * (size_t)D->cap_rays};
+                       D->d_park, D->d_park + D->cap_rays, D->d_park + 2 * (size_t)D->cap_rays, D->d_seg + 8 * BHRT_ORDER_SHARDS + 3};
         HIP_CHECK(hipMemsetAsync(D->d_cnt, 0, sizeof(Counters), D->stream));
         HIP_CHECK(hipMemsetAsync(D->d_samples, 0, (size_t)npx * o.spp * 3 * sizeof(float), D->stream));
         const uint32_t total = npx * (uint32_t)o.spp;
@@ -1562,7 +1575,7 @@ int bhrt_scene_upload(bhrt_scene *scene, int device)
     HIP_CHECK(hipMalloc(&D->d_chain, chain.size() * sizeof(int32_t)));
     HIP_CHECK(hipMemcpy(D->d_chain, chain.data(), chain.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&D->d_cnt, sizeof(Counters)));
-    HIP_CHECK(hipMalloc(&D->d_seg, (8 * BHRT_ORDER_SHARDS + 3) * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&D->d_seg, (11 * BHRT_ORDER_SHARDS + 3) * sizeof(uint32_t)));
     HIP_CHECK(hipHostMalloc(&D->h_cnt, sizeof(Counters)));
     HIP_CHECK(hipEventCreateWithFlags(&D->ev_counts, hipEventDisableTiming));
     DevScene &S = D->S;
@@ -1611,7 +1624,7 @@ int bhrt_trace_closest_dev(bhrt_scene *scene, const float *d_rays_soa, int hit_s
     RayQueue q = MakeRayQueue(const_cast<float *>(d_rays_soa), nullptr, n);
     HitBuf h; h.t = d_out.t; h.node = d_out.node; h.prim = d_out.prim; h.front = d_out.front;
     hipStream_t s = stream ? (hipStream_t)stream : scene->dev->stream;
-    RayOrder no_order = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    RayOrder no_order = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, false>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, PassInfo(), q, (uint32_t)n, hit_side, h, no_order, (Counters *)nullptr);
     HIP_CHECK(hipGetLastError());
     if (!stream) HIP_CHECK(hipStreamSynchronize(s));
