@@ -1423,7 +1423,8 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         RayOrder RO = {D->d_order, D->order_shard_cap, D->d_seg, D->d_seg + 3 * BHRT_ORDER_SHARDS + 1, D->d_seg + 6 * BHRT_ORDER_SHARDS + 1, D->d_seg + 7 * BHRT_ORDER_SHARDS + 2,
                        D->d_park, D->d_park + D->cap_rays, D->d_park + 2 * (size_t)D->cap_rays, D->d_seg + 8 * BHRT_ORDER_SHARDS + 3};
         HIP_CHECK(hipMemsetAsync(D->d_cnt, 0, sizeof(Counters), D->stream));
-        HIP_CHECK(hipMemsetAsync(D->d_samples, 0, (size_t)npx * o.spp * 3 * sizeof(float), D->stream));
+        // d_samples needs no clearing: every slot of a valid pixel is written exactly once (k_shade: background of a camera
+        // miss; k_combine: root frame), and k_resolve never reads the slots of edge-tile pixels outside the image
         const uint32_t total = npx * (uint32_t)o.spp;
         uint32_t n_cur = total; // first wave step: one slot per (pixel, sample); the kernels compute the camera rays themselves
         bool first_step = true;
