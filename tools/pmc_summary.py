@@ -82,6 +82,16 @@ def main():
                     ent["valu_active_share_of_wave_time"] = s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"]
             out[k] = ent
             per_launch[k + "_bytes_per_launch"] = (rd + wr) / n
+        # the closest-hit trace of a wave step is k_trace_closest + (scenes with meshes) the parked-ray finish and its sort;
+        # bench.py times them as one unit, so their traffic is summed per trace launch as well
+        group = [k for k in out if k in ("k_trace_closest", "k_trace_mesh", "k_park_count", "k_park_scatter", "k_scan_tiles", "k_scan_sums", "k_scan_add")]
+        if "k_trace_closest" in out:
+            n = out["k_trace_closest"]["launches"]
+            per_launch["k_trace_closest_bytes_per_launch"] = sum(out[k]["read_bytes"] + out[k]["written_bytes"] for k in group) / n
+        group = [k for k in out if k in ("k_trace_shadow", "k_trace_shadow_park", "k_shadow_mesh")]
+        if group:
+            n = max(out[k]["launches"] for k in group)
+            per_launch["k_trace_shadow_bytes_per_launch"] = sum(out[k]["read_bytes"] + out[k]["written_bytes"] for k in group) / n
         json.dump(out, open(os.path.join(dst, f"{wl}_pmc_one_frame.json"), "w"), indent=1)
         traffic[wl] = per_launch
     traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/pmc_workload.py (one frame), "
