@@ -122,7 +122,8 @@ __device__ inline uint32_t sample_addr(const PassInfo &P, uint32_t slot) { retur
 __device__ inline void put_ray(const RayQueue &q, uint32_t i, V3 o, V3 d, uint32_t frame, uint32_t meta, uint32_t ctr)
 {
     q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z; q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
-    q.frame[i] = frame; q.meta[i] = meta; q.rng_ctr[i] = ctr;
+    q.frame[i] = frame; q.meta[i] = meta;
+    if ((meta & 15u) != RK_GI) q.rng_ctr[i] = ctr; // only a refraction chain carries its stream position along
 }
 __device__ inline uint32_t make_meta(uint32_t kind, uint32_t side, int bounce) { return kind | (side << 4) | ((uint32_t)(bounce & 0xff) << 8); }
 __device__ inline void st3(float *a, uint32_t i, V3 v) { a[3 * (size_t)i] = v.x; a[3 * (size_t)i + 1] = v.y; a[3 * (size_t)i + 2] = v.z; }
@@ -400,7 +401,7 @@ struct ShadeOut {
     V3 so, sd; float stmax;          // shadow ray
 };
 
-__device__ inline void shade_entry(const DevScene &S, const RenderParams &R, const Frames &F, uint32_t f, V3 rayP, const Attr &a, int node,
+__device__ inline void shade_entry(const DevScene &S, const RenderParams &R, const Frames &F, uint32_t f, uint32_t how, V3 rayP, const Attr &a, int node,
                                    int bounce, int gi, uint64_t code, uint32_t skey, ShadeOut &out)
 {
     out.has_refr = out.has_gi = out.has_shadow = false;
@@ -413,7 +414,7 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
         // node without material: black (the reference dereferences null); empty MultiMtl: white (materials.h:71)
         flags = FF_CONST;
         st3(F.refr, f, (mi >= 0 && S.materials[mi].kind == BHRT_MTL_WHITE) ? v3(1, 1, 1) : zero);
-        F.info[f] = (F.info[f] & 7u) | (flags << 16);
+        F.info[f] = how | (flags << 16);
         return;
     }
     const bhrt_material &m = S.materials[mi];
@@ -524,7 +525,7 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
         st3(F.ph_kd, f, textured ? tc_sample_d(S, m.diffuse, a.uvw, a.du, a.dv) : ld3(m.diffuse.color));
         st3(F.ph_ks, f, textured ? tc_sample_d(S, newSpecular, a.uvw, a.du, a.dv) : ld3(newSpecular.color));
     }
-    F.info[f] = (F.info[f] & 7u) | (dmode << 3) | (light_idx << 8) | (flags << 16) | ((uint32_t)(mi & 0xfff) << 20);
+    F.info[f] = how | (dmode << 3) | (light_idx << 8) | (flags << 16) | ((uint32_t)(mi & 0xfff) << 20); // the frame's only write of info
 }
 
 #ifndef BHRT_SHADE_WAVES
@@ -563,7 +564,7 @@ __global__ void __launch_bounds__(kShadeBlock, BHRT_SHADE_WAVES) k_shade(DevScen
     }
     if (active) {
         if (kCamera) { owner = i; ctr = 0; } // the sample slot
-        else { owner = qin.frame[i]; ctr = qin.rng_ctr[i]; }
+        else { owner = qin.frame[i]; ctr = (meta & 15u) != RK_GI ? qin.rng_ctr[i] : 0u; }
         hit.t = hb.t[i]; hit.node = hb.node[i]; hit.prim = hb.prim[i]; hit.front = hb.front[i];
     }
     const uint32_t kind = meta & 15u;
@@ -609,7 +610,6 @@ __global__ void __launch_bounds__(kShadeBlock, BHRT_SHADE_WAVES) k_shade(DevScen
                 code = pcode * 2 + 1;
                 how = FH_GI;
                 bounce = (int)((pi2 >> 8) & 0xffu); // Shade(GIRay, ..., o_bounceCount, gi-1): the parent's own bounce count
-                mult = ld3i(F.gi_mult, owner);
             } else if (kind == RK_REFR_IN) {
                 code = pcode * 2;
                 how = FH_REFR_FRONT;
@@ -624,16 +624,15 @@ __global__ void __launch_bounds__(kShadeBlock, BHRT_SHADE_WAVES) k_shade(DevScen
             }
         }
         F.parent[f] = owner;
-        F.info[f] = how;
         F.info2[f] = (uint32_t)(gi + 64) | ((uint32_t)(bounce & 0xff) << 8);
         F.skey[f] = skey;
         F.code[f] = code;
-        if (how == FH_GI || how == FH_REFR_OUT) st3(F.mult, f, mult);
+        if (how == FH_REFR_OUT) st3(F.mult, f, mult); // a GI frame's multiplier stays where it is: the parent's gi_mult (k_combine)
         const int mi = S.nodes[hit.node].material;
         const bool need_uv = mi >= 0 && (S.materials[mi].diffuse.map >= 0 || S.materials[mi].specular.map >= 0);
         Attr a;
         hit_attrs(S, o, d, hit.t, hit.node, hit.prim, need_uv, a);
-        shade_entry(S, R, F, f, o, a, hit.node, bounce, gi, code, skey, so);
+        shade_entry(S, R, F, f, how, o, a, hit.node, bounce, gi, code, skey, so);
         ray_owner = f;
     } else if (active) {
         if (kind == RK_CAMERA) {
@@ -772,7 +771,7 @@ __global__ void __launch_bounds__(kBlock) k_combine(DevScene S, PassInfo P, Fram
     const uint32_t parent = F.parent[f];
     if (how == FH_ROOT) st3(samples, sample_addr(P, parent), out);
     else if (how == FH_GI) { // MtlBlinn.cpp:406,427-432
-        V3 oc = v3(0, 0, 0) + out * ld3i(F.mult, f);
+        V3 oc = v3(0, 0, 0) + out * ld3i(F.gi_mult, parent);
         if (isnan_f(oc.x)) oc = v3(1.0f, 0.0f, 1.0f);
         else oc = clamp_white(oc);
         st3(F.gi, parent, oc);
