@@ -88,21 +88,22 @@ __device__ inline RayRcp ray_rcp(V3 d)
     r.rx = 1.0 / (double)d.x; r.ry = 1.0 / (double)d.y; r.rz = 1.0 / (double)d.z;
     return r;
 }
-__device__ inline float div_shared(float a, float d, double rd)
+// One quotient of the shared-reciprocal slab test and its validity: the exponent field must lie in [28, 226]
+// (2^-99 <= |q| < 2^100: a normal, finite, non-zero quotient).  Zero, subnormal, huge, inf and NaN quotients — which is
+// also what a zero direction component produces through rd = inf — send the WHOLE box to the plain-division form.
+__device__ inline float mul_shared(float a, double rd, uint32_t &bad)
 {
     const float q = (float)((double)a * rd);
-    const float aq = fabsf(q);
-    if (aq > 1e-30f && aq < 1e30f) return q; // normal range (also excludes NaN / inf / zero results)
-    return a / d;
+    bad |= (((__float_as_uint(q) >> 23) & 0xffu) - 28u) > 198u ? 1u : 0u;
+    return q;
 }
 __device__ inline bool box_hit_rcp(const float *b, V3 o, V3 d, const RayRcp &r, float t_max, float &t_min)
 {
-    float tz1 = (d.z != 0) ? div_shared(b[2] - o.z, d.z, r.rz) : BHRT_BIGFLOAT;
-    float tz2 = (d.z != 0) ? div_shared(b[5] - o.z, d.z, r.rz) : -BHRT_BIGFLOAT;
-    float ty1 = (d.y != 0) ? div_shared(b[1] - o.y, d.y, r.ry) : BHRT_BIGFLOAT;
-    float ty2 = (d.y != 0) ? div_shared(b[4] - o.y, d.y, r.ry) : -BHRT_BIGFLOAT;
-    float tx1 = (d.x != 0) ? div_shared(b[0] - o.x, d.x, r.rx) : BHRT_BIGFLOAT;
-    float tx2 = (d.x != 0) ? div_shared(b[3] - o.x, d.x, r.rx) : -BHRT_BIGFLOAT;
+    uint32_t bad = 0;
+    const float tz1 = mul_shared(b[2] - o.z, r.rz, bad), tz2 = mul_shared(b[5] - o.z, r.rz, bad);
+    const float ty1 = mul_shared(b[1] - o.y, r.ry, bad), ty2 = mul_shared(b[4] - o.y, r.ry, bad);
+    const float tx1 = mul_shared(b[0] - o.x, r.rx, bad), tx2 = mul_shared(b[3] - o.x, r.rx, bad);
+    if (bad) return box_hit(b, o, d, t_max, t_min); // rare: one branch per box instead of one per quotient
     float tMin = fmax_cy(fmax_cy(fmin_cy(tx1, tx2), fmin_cy(ty1, ty2)), fmin_cy(tz1, tz2));
     float tMax = fmin_cy(fmin_cy(fmax_cy(tx1, tx2), fmax_cy(ty1, ty2)), fmax_cy(tz1, tz2));
     if (tMin <= tMax && tMin < t_max) { t_min = tMin; return true; }
