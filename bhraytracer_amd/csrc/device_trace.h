@@ -131,16 +131,19 @@ __device__ inline bool tri_areas(V3 v0, V3 v1, V3 v2, V3 vN, V3 vX, float &a0, f
 // vN, |vN| and vN.v0 come precomputed with the triangle (same float operations as TriObj.cpp:79,85,89)
 __device__ inline bool tri_hit(const bhrt_tri &tr, V3 o, V3 d, float dlen, int side, float t_cur, float &t_out, int &front_out)
 {
+    // The reference returns at each failed test; here the cheap tests are evaluated straight through and AND-ed (a wave
+    // of 64 rays almost always has a lane that passes each of them, so the early returns only cost branches), with one
+    // branch left in front of the barycentric part.  Divisions by zero only feed predicates that are already false.
     V3 vN = ld3(tr.vN);
     float t_divisor = dot(vN, d);
-    if (t_divisor == 0) return false;
+    bool ok = t_divisor != 0;
     float perp = t_divisor / (tr.vN_len * dlen);
-    if (perp > -BHRT_PERP && perp < BHRT_PERP) return false;
+    ok = ok && !(perp > -BHRT_PERP && perp < BHRT_PERP);
     float t = (tr.vN_dot_v0 - dot(vN, o)) / t_divisor;
-    if (t <= 0 || t > t_cur) return false;
+    ok = ok && !(t <= 0 || t > t_cur);
     bool hitFront = t_divisor < 0;
-    if (!hitFront && side == BHRT_HIT_FRONT) return false;
-    else if (hitFront && side == BHRT_HIT_BACK) return false;
+    ok = ok && !(!hitFront && side == BHRT_HIT_FRONT) && !(hitFront && side == BHRT_HIT_BACK);
+    if (!ok) return false;
     V3 v0 = ld3(tr.v0), v1 = ld3(tr.v1), v2 = ld3(tr.v2);
     V3 vX = o + t * d;
     float a0, a1, a2;
