@@ -401,6 +401,9 @@ struct ShadeOut {
     V3 so, sd; float stmax;          // shadow ray
 };
 
+// kTex = false: the scene has no texture map at all (every TexturedColor is its plain colour): the texture sampling code
+// (a quarter of the kernel, 200 divisions) is not even compiled in.
+template <bool kTex>
 __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, const Frames &F, uint32_t f, uint32_t how, V3 rayP, const Attr &a, int node,
                                    int bounce, int gi, uint64_t code, uint32_t skey, ShadeOut &out)
 {
@@ -468,7 +471,7 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
         flags |= FF_HAS_REFR;
     }
     // ---- global illumination, PathTracing_GlobalIllumination (MtlBlinn.cpp:383-433)
-    const bool textured = m.diffuse.map >= 0 || newSpecular.map >= 0;
+    const bool textured = kTex && (m.diffuse.map >= 0 || newSpecular.map >= 0);
     if (gi >= 0) {
         DRng g;
         g.key = bhrt_section_key(skey, code, BHRT_SEC_GI);
@@ -531,7 +534,7 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
 #ifndef BHRT_SHADE_WAVES
 #define BHRT_SHADE_WAVES 4 /* waves per SIMD the register allocation must allow */
 #endif
-template <bool kCamera>
+template <bool kCamera, bool kTex>
 __global__ void __launch_bounds__(kShadeBlock, BHRT_SHADE_WAVES) k_shade(DevScene S, RenderParams R, PassInfo P, RayQueue qin, HitBuf hb, uint32_t n, RayQueue qout,
                                                    ShadowQueue qs, Frames F, float *samples, Counters *cnt, RayOrder ord)
 {
@@ -629,17 +632,17 @@ __global__ void __launch_bounds__(kShadeBlock, BHRT_SHADE_WAVES) k_shade(DevScen
         F.code[f] = code;
         if (how == FH_REFR_OUT) st3(F.mult, f, mult); // a GI frame's multiplier stays where it is: the parent's gi_mult (k_combine)
         const int mi = S.nodes[hit.node].material;
-        const bool need_uv = mi >= 0 && (S.materials[mi].diffuse.map >= 0 || S.materials[mi].specular.map >= 0);
+        const bool need_uv = kTex && mi >= 0 && (S.materials[mi].diffuse.map >= 0 || S.materials[mi].specular.map >= 0);
         Attr a;
         hit_attrs(S, o, d, hit.t, hit.node, hit.prim, need_uv, a);
-        shade_entry(S, R, F, f, how, o, a, hit.node, bounce, gi, code, skey, so);
+        shade_entry<kTex>(S, R, F, f, how, o, a, hit.node, bounce, gi, code, skey, so);
         ray_owner = f;
     } else if (active) {
         if (kind == RK_CAMERA) {
             // background.Sample((i/W, j/H, 0)), Main.cpp:166-167
             int pi, pj;
             pixel_of(P, P.q0 + owner / (uint32_t)P.spp, pi, pj);
-            st3(samples, sample_addr(P, owner), tc_sample(S, S.background, v3((float)pi / S.cam.width, (float)pj / S.cam.height, 0.0f)));
+            st3(samples, sample_addr(P, owner), kTex ? tc_sample(S, S.background, v3((float)pi / S.cam.width, (float)pj / S.cam.height, 0.0f)) : ld3(S.background.color));
         } else if (kind == RK_GI) {
             V3 mult = ld3i(F.gi_mult, owner);
             V3 outc = v3(0, 0, 0);
@@ -648,7 +651,7 @@ __global__ void __launch_bounds__(kShadeBlock, BHRT_SHADE_WAVES) k_shade(DevScen
             } else if (d.x == d.y && d.x == 0) {
                 outc = outc + v3(1.0f, 0.0f, 1.0f); // MtlBlinn.cpp:411-415
             } else {
-                V3 env = sample_environment(S, S.environment, d) * mult;
+                V3 env = (kTex ? sample_environment(S, S.environment, d) : ld3(S.environment.color)) * mult;
                 if (!(isnan_f(env.x) || isnan_f(env.y) || isnan_f(env.z))) outc = outc + env;
             }
             if (isnan_f(outc.x)) outc = v3(1.0f, 0.0f, 1.0f);
@@ -705,7 +708,7 @@ __global__ void __launch_bounds__(kShadeBlock, BHRT_SHADE_WAVES) k_shade(DevScen
                 }
             }
         } else { // RK_REFR_OUT miss: refraction * environment (MtlBlinn.cpp:535-539)
-            st3(F.refr, owner, clamp_white(ld3i(F.refr_color, owner) * sample_environment(S, S.environment, d)));
+            st3(F.refr, owner, clamp_white(ld3i(F.refr_color, owner) * (kTex ? sample_environment(S, S.environment, d) : ld3(S.environment.color))));
         }
     }
 
@@ -1458,8 +1461,9 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             {
                 Timer t(D, &st->seconds_shade);
                 const dim3 sg((n_cur + kShadeBlock - 1) / kShadeBlock + 3 * BHRT_ORDER_SHARDS), sb(kShadeBlock);
-                if (first_step) hipLaunchKernelGGL(k_shade<true>, sg, sb, 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt, RO);
-                else hipLaunchKernelGGL(k_shade<false>, sg, sb, 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt, RO);
+                const bool tex = H->n_texmaps > 0;
+                auto shade = first_step ? (tex ? k_shade<true, true> : k_shade<true, false>) : (tex ? k_shade<false, true> : k_shade<false, false>);
+                hipLaunchKernelGGL(shade, sg, sb, 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt, RO);
                 t.Stop();
             }
             HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, BHRT_COUNTERS_HOST_BYTES, hipMemcpyDeviceToHost, D->stream)); // n_next, n_shadow, n_frames, overflow
