@@ -204,6 +204,10 @@ BHRT_DM double exp_d(double z)
 BHRT_DM float powf_(float xf, float yf)
 {
     double x = xf, y = yf;
+    // The case this path produces almost always — positive finite base, finite exponent — first and behind ONE branch
+    // (the special cases below are a dozen branch points that every call used to walk through).  x == 1 and y == 0 need
+    // no special case here: log_pos_d(1) is exactly 0 and exp_d(+-0) exactly 1.
+    if (x > 0.0 && x < inf_d() && fabs_d(y) < inf_d()) return (float)exp_d(y * log_pos_d(x));
     if (y == 0.0) return 1.0f;
     if (x == 1.0) return 1.0f;
     if (isnan_d(x) || isnan_d(y)) return bitsf(0x7fc00000u);
