@@ -32,6 +32,7 @@ static_assert(sizeof(DPhoton) == 24, "photon record must be 24 bytes");
 
 #define BHRT_PHOTON_ABSORB 0.3f /* Photon_AbsorbChance, MtlBlinn.cpp:27 */
 #define BHRT_PHOTON_K 1000      /* MAX_PhotonCountInArea, MtlBlinn.cpp:28 */
+#define BHRT_HEAP_COLUMN 1002   /* entries of one query's candidate column: slot 0 unused, 1..1000, one pad (16-byte pairs) */
 
 BHRT_FN uint8_t float_to_byte(float r) // Color24::FloatToByte, cyColor.h:271-272
 {
@@ -410,9 +411,16 @@ __device__ inline int photon_estimate_wave(const PhotonMapDev &M, WaveGatherLds 
 // (dist2 >= 0: the float order is the order of the bit patterns, but the comparisons below stay float comparisons).
 __device__ inline float cand_d2(unsigned long long e) { return __uint_as_float((uint32_t)(e >> 32)); }
 __device__ inline unsigned long long make_cand(float d2, uint32_t idx) { return ((unsigned long long)__float_as_uint(d2) << 32) | idx; }
-__device__ inline bool photon_estimate_heap(const PhotonMapDev &M, V3 pos, V3 normal, float radius, unsigned long long *cand, size_t stride,
+// child pair (2j, 2j+1) of the candidate heap in one 16-byte load (the column is 16-byte aligned, 2j is even)
+__device__ inline void cand_pair(const unsigned long long *cand, int j, unsigned long long &c0, unsigned long long &c1)
+{
+    const ulonglong2 v = *(const ulonglong2 *)(cand + j);
+    c0 = v.x; c1 = v.y;
+}
+__device__ inline bool photon_estimate_heap(const PhotonMapDev &M, V3 pos, V3 normal, float radius, unsigned long long *cand, size_t /*stride = 1*/,
                                             V3 &irrad, V3 &direction)
 {
+    constexpr size_t stride = 1;
     irrad = v3(0, 0, 0);
     direction = v3(0, 0, 0);
     if (M.n <= 0) return false;
@@ -437,11 +445,9 @@ __device__ inline bool photon_estimate_heap(const PhotonMapDev &M, V3 pos, V3 no
                     const float td2 = cand_d2(t);
                     while (parent <= half_found) {
                         int j = parent + parent;
-                        unsigned long long cj = cand[(size_t)j * stride];
-                        if (j < found) {
-                            const unsigned long long cj1 = cand[(size_t)(j + 1) * stride];
-                            if (cand_d2(cj) < cand_d2(cj1)) { j++; cj = cj1; }
-                        }
+                        unsigned long long cj, cj1;
+                        cand_pair(cand, j, cj, cj1);
+                        if (j < found && cand_d2(cj) < cand_d2(cj1)) { j++; cj = cj1; }
                         if (td2 >= cand_d2(cj)) break;
                         cand[(size_t)parent * stride] = cj;
                         parent = j;
@@ -452,11 +458,9 @@ __device__ inline bool photon_estimate_heap(const PhotonMapDev &M, V3 pos, V3 no
         } else {
             int parent = 1, j = 2;
             while (j <= found) {
-                unsigned long long cj = cand[(size_t)j * stride];
-                if (j < found) {
-                    const unsigned long long cj1 = cand[(size_t)(j + 1) * stride];
-                    if (cand_d2(cj) < cand_d2(cj1)) { j++; cj = cj1; }
-                }
+                unsigned long long cj, cj1;
+                cand_pair(cand, j, cj, cj1);
+                if (j < found && cand_d2(cj) < cand_d2(cj1)) { j++; cj = cj1; }
                 if (dist2 > cand_d2(cj)) break;
                 cand[(size_t)parent * stride] = cj;
                 parent = j;

@@ -1042,7 +1042,7 @@ __global__ void __launch_bounds__(kBlock) k_photon_gather_heap(Sink sink, const 
     if (lane >= cnt) return;
     const uint32_t q = heavy[h0 + lane];
     V3 irr, d;
-    const bool found = photon_estimate_heap(M, sink.pos(q), sink.nrm(q), radius, scr + lane, stride, irr, d);
+    const bool found = photon_estimate_heap(M, sink.pos(q), sink.nrm(q), radius, scr + (size_t)lane * BHRT_HEAP_COLUMN, 1, irr, d);
     sink.done(q, found, irr, d);
 }
 
@@ -1296,7 +1296,7 @@ static int EnsurePhotonScratch(DeviceState *D, uint32_t lanes)
     if (D->scr_lanes >= lanes) return BHRT_OK;
     if (D->d_scr) (void)hipFree(D->d_scr);
     D->d_scr = nullptr; D->scr_lanes = 0;
-    HIP_CHECK(hipMalloc(&D->d_scr, (size_t)lanes * (BHRT_PHOTON_K + 1) * sizeof(unsigned long long)));
+    HIP_CHECK(hipMalloc(&D->d_scr, (size_t)lanes * BHRT_HEAP_COLUMN * sizeof(unsigned long long)));
     D->scr_lanes = lanes;
     return BHRT_OK;
 }
