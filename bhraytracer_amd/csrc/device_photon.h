@@ -203,44 +203,34 @@ struct PhotonMapDev {
     float lo[3], hi[3]; // bounds of the photon positions
 };
 
-struct PhotonWalk { // stackless walk over the balanced kd-tree in the order of LocatePhotons (cyPhotonMap.h:421-498)
-    int idx = 1, from = 0;
-    bool desc = true;
+// Stackless walk over the balanced kd-tree in the order of LocatePhotons (cyPhotonMap.h:421-498), as ONE uniform step
+// per loop iteration: every lane loads one node and either moves on (to the near child, to the far child, or back up)
+// or reports that the node's own photon is due.  All decisions are selects — a lane-per-query walk written with nested
+// loops ran with 7 of 64 lanes active (each lane in a different loop); in this form only the "photon due" part is a
+// divergent block.
+struct PhotonWalk {
+    int cur = 1, from = 0; // node to handle next; the child we came back from (0 = arriving from the parent)
+    bool done = false;
 };
-// Advances to the next node whose own photon is due (its hot record in `rec`); false when the walk is over.
-// d2max is the CURRENT squared radius.
-__device__ inline bool photon_walk_next(const PhotonMapDev &M, PhotonWalk &w, V3 pos, float d2max, int &node, float4 &rec)
+// One step.  Returns true when the own photon of node `node` (hot record `rec`) is due.  d2max = CURRENT squared radius.
+__device__ inline bool photon_walk_step(const PhotonMapDev &M, PhotonWalk &w, V3 pos, float d2max, int &node, float4 &rec)
 {
-    while (true) {
-        if (w.desc) {
-            const float4 h = M.hot[w.idx];
-            if (w.idx < M.half) {
-                const int axis = (int)__float_as_uint(h.w);
-                const float dist = (axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z)) - (axis == 0 ? h.x : (axis == 1 ? h.y : h.z));
-                w.idx = dist > 0 ? 2 * w.idx + 1 : 2 * w.idx;
-                continue;
-            }
-            node = w.idx;
-            rec = h;
-        } else {
-            if (w.from == 1) return false;
-            const int par = w.from >> 1;
-            const float4 h = M.hot[par];
-            const int axis = (int)__float_as_uint(h.w);
-            const float dist = (axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z)) - (axis == 0 ? h.x : (axis == 1 ? h.y : h.z));
-            const int firstc = dist > 0 ? 2 * par + 1 : 2 * par;
-            if (w.from == firstc && dist * dist < d2max) {
-                w.idx = firstc ^ 1;
-                w.desc = true;
-                continue;
-            }
-            node = par;
-            rec = h;
-        }
-        w.from = node;
-        w.desc = false;
-        return true;
-    }
+    const int cur = w.cur;
+    const float4 h = M.hot[cur];
+    const int axis = (int)__float_as_uint(h.w);
+    const float dist = (axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z)) - (axis == 0 ? h.x : (axis == 1 ? h.y : h.z));
+    const int nearc = dist > 0 ? 2 * cur + 1 : 2 * cur;
+    const bool arriving = w.from == 0;
+    const bool down_near = arriving && cur < M.half;                            // LocatePhotons recurses only below `half` (Q11)
+    const bool down_far = !arriving && w.from == nearc && dist * dist < d2max;  // back from the near side: far side if the plane is within the radius
+    const bool due = !(down_near || down_far);                                  // leaf on arrival, or both sides done
+    node = cur;
+    rec = h;
+    // transitions
+    w.done = due && cur == 1;
+    w.cur = down_near ? nearc : (down_far ? (nearc ^ 1) : (cur >> 1));
+    w.from = due ? cur : 0;
+    return due;
 }
 __device__ inline bool photon_outside_bounds(const PhotonMapDev &M, V3 pos, float radius)
 {
@@ -274,7 +264,8 @@ __device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 nor
     PhotonWalk w;
     int node;
     float4 h;
-    while (photon_walk_next(M, w, pos, d2max, node, h)) {
+    while (!w.done) {
+        if (!photon_walk_step(M, w, pos, d2max, node, h)) continue;
         if (--budget < 0) return 3;
         const float dist2 = length_sq(v3(h.x, h.y, h.z) - pos);
         if (dist2 < d2max) {
@@ -420,60 +411,63 @@ __device__ inline void cand_pair(const unsigned long long *cand, int j, unsigned
 __device__ inline bool photon_estimate_heap(const PhotonMapDev &M, V3 pos, V3 normal, float radius, unsigned long long *cand, size_t /*stride = 1*/,
                                             V3 &irrad, V3 &direction)
 {
-    constexpr size_t stride = 1;
+    // The walk advances by uniform steps (photon_walk_step); the sift-downs stay inner loops.  (Tried and slower: every sift
+    // LEVEL as a step of one flat loop, +27 %; a two-phase loop "all lanes walk to their next candidate, then sift
+    // together", +9 %.)
     irrad = v3(0, 0, 0);
     direction = v3(0, 0, 0);
     if (M.n <= 0) return false;
     float d2max = radius * radius; // np.dist2[0]
     int found = 0;
+    constexpr int kHalf = BHRT_PHOTON_K >> 1;
     PhotonWalk w;
-    int node;
-    float4 h;
-    while (photon_walk_next(M, w, pos, d2max, node, h)) {
+    while (!w.done) {
+        int node;
+        float4 h;
+        if (!photon_walk_step(M, w, pos, d2max, node, h)) continue;
         const float dist2 = length_sq(v3(h.x, h.y, h.z) - pos);
         if (!(dist2 < d2max)) continue;
         const float4 c0 = M.cold[2 * (size_t)node];
         if (dot(v3(c0.x, c0.y, c0.z), normal) >= 0) continue;
         if (found < BHRT_PHOTON_K) {
             found++;
-            cand[(size_t)found * stride] = make_cand(dist2, (uint32_t)node);
-            if (found == BHRT_PHOTON_K) { // build the max-heap
-                const int half_found = found >> 1;
-                for (int k = half_found; k >= 1; k--) {
+            cand[found] = make_cand(dist2, (uint32_t)node);
+            if (found == BHRT_PHOTON_K) { // build the max-heap (cyPhotonMap.h:458-476)
+                for (int k = kHalf; k >= 1; k--) {
                     int parent = k;
-                    const unsigned long long t = cand[(size_t)k * stride];
+                    const unsigned long long t = cand[k];
                     const float td2 = cand_d2(t);
-                    while (parent <= half_found) {
+                    while (parent <= kHalf) {
                         int j = parent + parent;
                         unsigned long long cj, cj1;
                         cand_pair(cand, j, cj, cj1);
-                        if (j < found && cand_d2(cj) < cand_d2(cj1)) { j++; cj = cj1; }
+                        if (j < BHRT_PHOTON_K && cand_d2(cj) < cand_d2(cj1)) { j++; cj = cj1; }
                         if (td2 >= cand_d2(cj)) break;
-                        cand[(size_t)parent * stride] = cj;
+                        cand[parent] = cj;
                         parent = j;
                     }
-                    cand[(size_t)parent * stride] = t;
+                    cand[parent] = t;
                 }
             }
-        } else {
-            int parent = 1, j = 2;
-            while (j <= found) {
+        } else { // replace the maximum (cyPhotonMap.h:478-495)
+            int parent = 1;
+            while (parent <= kHalf) {
+                int j = parent + parent;
                 unsigned long long cj, cj1;
                 cand_pair(cand, j, cj, cj1);
-                if (j < found && cand_d2(cj) < cand_d2(cj1)) { j++; cj = cj1; }
+                if (j < BHRT_PHOTON_K && cand_d2(cj) < cand_d2(cj1)) { j++; cj = cj1; }
                 if (dist2 > cand_d2(cj)) break;
-                cand[(size_t)parent * stride] = cj;
+                cand[parent] = cj;
                 parent = j;
-                j <<= 1;
             }
-            cand[(size_t)parent * stride] = make_cand(dist2, (uint32_t)node);
-            d2max = cand_d2(cand[(size_t)1 * stride]);
+            cand[parent] = make_cand(dist2, (uint32_t)node);
+            d2max = cand_d2(cand[1]);
         }
     }
     if (found == 0) return false;
     V3 sumI = v3(0, 0, 0), sumD = v3(0, 0, 0); // list order: insertion order below 1000 photons, heap-array order from there on
     for (int i = 1; i <= found; i++) {
-        const size_t k = (uint32_t)cand[(size_t)i * stride];
+        const size_t k = (uint32_t)cand[i];
         const float4 c0 = M.cold[2 * k], c1 = M.cold[2 * k + 1];
         sumI = sumI + 1.f * v3(c1.x, c1.y, c1.z);
         sumD = sumD + v3(c0.x, c0.y, c0.z) * (1.f * c0.w);
