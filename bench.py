@@ -157,16 +157,24 @@ def main():
         photon_build_s = time.perf_counter() - t0
         opts.photon_map = 1
 
-    d_rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
-    d_rad = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-
-    gather_scratch = {}
+    # Two frame buffers (+ exchange scratch) used alternately: the exchange of frame k (torch's stream) overlaps the
+    # rendering of frame k+1 (the library's stream); a buffer is rendered into again only after its last exchange is done.
+    n_buf = 2 if N > 1 else 1
+    bufs = [(torch.zeros((H, W, 3), dtype=torch.uint8, device=dev), torch.zeros((H, W, 3), dtype=torch.float32, device=dev), {},
+             torch.cuda.Event()) for _ in range(n_buf)]
+    d_rgb, d_rad = bufs[0][0], bufs[0][1]
+    frame_no = [0]
 
     def step():
-        st = sc.render_dev(opts, d_rgb.data_ptr(), d_rad.data_ptr())
+        rgb, rad, scratch, ev = bufs[frame_no[0] % n_buf]
+        frame_no[0] += 1
+        if N > 1:
+            ev.synchronize()  # no-op until the event has been recorded once
+        st = sc.render_dev(opts, rgb.data_ptr(), rad.data_ptr())
         if N > 1:
             # pack -> ONE all_gather of byte blocks (RCCL; through the host with gloo when rehearsing on one GPU) -> unpack
-            BD.gather_frame_dev(d_rgb, d_rad, tile, rank, N, scratch=gather_scratch, via_host=args.rehearse_on_one_gpu)
+            BD.gather_frame_dev(rgb, rad, tile, rank, N, scratch=scratch, via_host=args.rehearse_on_one_gpu)
+            ev.record()
         return st
 
     def sync():
