@@ -303,10 +303,13 @@ def test_tile_exchange_pack_unpack(B):
 def test_logical_ranks_exchange_matches_single_rank_render():
     """Two processes on this GPU (gloo, blocks through the host): render own tiles, native pack -> all_gather -> native
     unpack, compare with the single-rank frame byte for byte (tools/verify_multi_rank.py).  RCCL itself needs one GPU per rank."""
-    import subprocess, sys
+    import socket, subprocess, sys
     from conftest import ROOT
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", os.path.join(ROOT, "tools", "verify_multi_rank.py")], env=env, capture_output=True, text=True, timeout=600)
+                        "--master-port", str(port), os.path.join(ROOT, "tools", "verify_multi_rank.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("identical") == 4 and "MISMATCH" not in r.stdout
