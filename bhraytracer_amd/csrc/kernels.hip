@@ -48,6 +48,9 @@ struct PassInfo {
     int32_t spp;
     uint32_t seed;
     int32_t jitter, gamma;
+    // per-frame constants of RandomPositionInPixel (Main.cpp:132-139), formed once on the host with the same float
+    // operations the reference performs per sample: unit dd_x, unit dd_y, |dd_x|
+    float jx[3], jy[3], pixel_len;
 };
 struct RenderParams {
     int32_t internal_bounces, gi_bounces;
@@ -144,8 +147,8 @@ __device__ inline bool camera_ray(const DevScene &S, const PassInfo &P, uint32_t
     const V3 topLeft = ld3(S.cam.top_left), ddx = ld3(S.cam.dd_x), ddy = ld3(S.cam.dd_y), pos = ld3(S.cam.pos);
     V3 target = (topLeft + (float)i * ddx) - (float)j * ddy;
     if (P.jitter) { // RandomPositionInPixel, Main.cpp:132-139: two raw rand() draws in double
-        const float pixelLen = length(ddx);
-        const V3 ux = normalized(ddx), uy = normalized(ddy);
+        const float pixelLen = P.pixel_len;
+        const V3 ux = ld3(P.jx), uy = ld3(P.jy);
         const uint32_t key = bhrt_sample_key(P.seed, (uint32_t)(j * P.W + i), s);
         float fx = (float)(((double)bhrt_rand31(key, 0) / (BHRT_RAND_MAX)) * 2 - 1);
         target = target + ((ux * fx) * pixelLen) / 2.f;
@@ -1387,6 +1390,12 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
     PassInfo P;
     P.W = W; P.H = Hh; P.tile = tile; P.tiles_x = (W + tile - 1) / tile; P.tiles_y = (Hh + tile - 1) / tile;
     P.rank = o.rank; P.world = world; P.spp = o.spp; P.seed = o.seed; P.jitter = o.jitter; P.gamma = o.gamma;
+    {
+        const V3 ddx = v3(H->camera.dd_x[0], H->camera.dd_x[1], H->camera.dd_x[2]), ddy = v3(H->camera.dd_y[0], H->camera.dd_y[1], H->camera.dd_y[2]);
+        const V3 ux = normalized(ddx), uy = normalized(ddy); // IEEE sqrt and divisions, no contraction: the bits the kernels used to compute per sample
+        P.jx[0] = ux.x; P.jx[1] = ux.y; P.jx[2] = ux.z; P.jy[0] = uy.x; P.jy[1] = uy.y; P.jy[2] = uy.z;
+        P.pixel_len = length(ddx);
+    }
     const uint32_t n_tiles = (uint32_t)(P.tiles_x * P.tiles_y);
     const uint32_t owned_tiles = n_tiles > (uint32_t)o.rank ? (n_tiles - (uint32_t)o.rank + (uint32_t)world - 1) / (uint32_t)world : 0;
     const uint64_t owned_pixels = (uint64_t)owned_tiles * tile * tile;
