@@ -43,12 +43,17 @@ def main():
         # last frame timeline from the kernel trace
         for f in glob.glob(os.path.join(src, f"trace_{wl}", "**", f"{wl}_kernel_trace.csv"), recursive=True):
             rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-            cams = [i for i, r in enumerate(rows) if "k_camera_rays" in r["Kernel_Name"]]
-            if cams:
-                t0 = int(rows[cams[-1]]["Start_Timestamp"])
+            # a frame ends with its last k_resolve: the last frame = everything after the previous frame's last k_resolve
+            res = [i for i, r in enumerate(rows) if "k_resolve" in r["Kernel_Name"]]
+            ends = [i for k, i in enumerate(res) if k + 1 == len(res) or res[k + 1] != i + 1]  # last k_resolve of each pass/frame
+            if len(ends) >= 2:
+                lo = ends[-2] + 1
+                while lo < len(rows) and "k_resolve" in rows[lo]["Kernel_Name"]:
+                    lo += 1
+                t0 = int(rows[lo]["Start_Timestamp"])
                 with open(os.path.join(dst, f"{wl}_last_frame_timeline.csv"), "w") as o:
                     o.write("kernel,start_us,duration_us,grid_size,workgroup_size,vgpr,lds_bytes\n")
-                    for r in rows[cams[-1]:]:
+                    for r in rows[lo:ends[-1] + 1]:
                         o.write(f"{short(r['Kernel_Name'])},{(int(r['Start_Timestamp']) - t0) / 1e3:.1f},"
                                 f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.1f},{r.get('Grid_Size_X', r.get('Grid_Size'))},"
                                 f"{r.get('Workgroup_Size_X', r.get('Workgroup_Size'))},{r.get('VGPR_Count', '')},{r.get('LDS_Block_Size', '')}\n")
