@@ -17,6 +17,11 @@ struct DevScene {
     const bhrt_texmap *texmaps;
     const bhrt_texture *textures;
     const int32_t *chain; // n_nodes x BHRT_MAX_NODE_DEPTH: ancestors of node n from depth 1 down to n itself
+    // per-material / per-light constants of Shade() that the reference recomputes on every call, formed once at upload with
+    // the same float operations: Schlick R0 (MtlBlinn.cpp:107) and the light-choice thresholds Gray(I) / allLightIntensity
+    // (MtlBlinn.cpp:311-318)
+    const float *mat_r0;     // [n_materials]
+    const float *light_pick; // [n_lights]
     int32_t n_nodes, n_lights;
     float all_light_intensity;
     bhrt_camera cam;

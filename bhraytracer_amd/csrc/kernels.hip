@@ -431,8 +431,7 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
     if (cosPhi1 <= 0) cosPhi1 = 0;
     const float ior = m.ior;
     // pow(float,int) is double pow in the reference (MtlBlinn.cpp:107-109); device math: repeated product
-    double r0d = (double)((1 - ior) / (1 + ior));
-    float R0 = (float)(r0d * r0d);
+    const float R0 = S.mat_r0[mi]; // (float)pow((1 - ior) / (1 + ior), 2): pow(float,int) is double pow in the reference (MtlBlinn.cpp:107)
     double omc = (double)(1 - cosPhi1);
     float fresnel = (float)(R0 + (1 - R0) * ((((omc * omc) * omc) * omc) * omc));
     V3 refrC = ld3(m.refraction.color);
@@ -494,7 +493,7 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
         g.ctr = 0;
         float rnd = g.rnd01();
         int li = 0;
-        while (rnd > gray3(S.lights[li].intensity) / S.all_light_intensity && li < S.n_lights - 1) li++;
+        while (rnd > S.light_pick[li] && li < S.n_lights - 1) li++;
         const bhrt_light &light = S.lights[li];
         light_idx = (uint32_t)li;
         V3 vL = sample_in_light(g, m.diffuse.color, newSpecular.color, light, a.p, m.glossiness);
@@ -1105,6 +1104,7 @@ struct DeviceState {
     int device = -1;
     uint8_t *d_blob = nullptr;
     int32_t *d_chain = nullptr;
+    float *d_aux = nullptr; // mat_r0 + light_pick (DevScene)
     DevScene S;
     // wavefront workspace
     uint32_t cap_samples = 0, cap_rays = 0, cap_frames = 0;
@@ -1160,7 +1160,7 @@ void DestroyDeviceState(DeviceState *d)
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     fr(d->d_blob); fr(d->d_chain);
     for (int k = 0; k < 2; k++) { fr(d->d_rayf[k]); fr(d->d_rayu[k]); }
-    fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_park); fr(d->d_seg); fr(d->d_cnt);
+    fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_park); fr(d->d_seg); fr(d->d_cnt); fr(d->d_aux);
     fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_cells); fr(d->d_tile_sums);
     if (d->h_n_heavy) (void)hipHostFree(d->h_n_heavy);
     if (d->h_cnt) (void)hipHostFree(d->h_cnt);
@@ -1604,6 +1604,21 @@ int bhrt_scene_upload(bhrt_scene *scene, int device)
     S.chain = D->d_chain;
     S.n_nodes = (int32_t)H->n_nodes; S.n_lights = (int32_t)H->n_lights;
     S.all_light_intensity = H->all_light_intensity;
+    {
+        const bhrt_material *mats = (const bhrt_material *)(scene->flat.blob.data() + H->off_materials);
+        const bhrt_light *lts = (const bhrt_light *)(scene->flat.blob.data() + H->off_lights);
+        std::vector<float> aux(H->n_materials + H->n_lights + 1, 0.f);
+        for (uint32_t m = 0; m < H->n_materials; m++) {
+            const float ior = mats[m].ior;
+            const double r0d = (double)((1 - ior) / (1 + ior));
+            aux[m] = (float)(r0d * r0d);
+        }
+        for (uint32_t l = 0; l < H->n_lights; l++) aux[H->n_materials + l] = ((lts[l].intensity[0] + lts[l].intensity[1] + lts[l].intensity[2]) / 3.0f) / H->all_light_intensity;
+        HIP_CHECK(hipMalloc(&D->d_aux, aux.size() * sizeof(float)));
+        HIP_CHECK(hipMemcpy(D->d_aux, aux.data(), aux.size() * sizeof(float), hipMemcpyHostToDevice));
+        S.mat_r0 = D->d_aux;
+        S.light_pick = D->d_aux + H->n_materials;
+    }
     S.cam = H->camera; S.background = H->background; S.environment = H->environment;
     S.tapx[0] = S.tapy[0] = 0;
     for (int i = 1; i < 32; i++) { // scene.h:322-329 with the deterministic sin/cos (host and device agree bit for bit)
