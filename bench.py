@@ -182,6 +182,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step()  # untimed: first use allocates the wavefront workspace (tens of GB of hipMalloc) — not part of any timed or warmup step
     for _ in range(args.warmup):
         step()
     sync()
