@@ -2,15 +2,19 @@
 //
 // One launch of each kernel processes one "wave step" of all paths in flight:
 //   camera_ray()    Main.cpp:132-153,179-192   the camera ray of a (pixel, sample) slot, computed inside the first step's kernels
-//   k_trace_closest Main.cpp:389-413 + Objects/* ordered scene-graph + BVH closest hit -> compact hits
-//   k_shade         MtlBlinn.cpp:89-589        one lane per traced ray: rebuilds the HitInfo, evaluates one
+//   k_trace_closest Main.cpp:389-413 + Objects/* ordered scene-graph closest hit -> compact hits; files every ray under its
+//                                              shading class; with meshes in the scene it parks the rays that enter a mesh
+//   k_trace_mesh    TriObj.cpp:17-39,192-270   the parked rays, key-sorted, in dense workgroups: BVH traversal + rest of the scene graph
+//   k_shade         MtlBlinn.cpp:89-589        one lane per traced ray, in class-sorted order: rebuilds the HitInfo, evaluates one
 //                                              Shade() entry or one refraction-chain step, emits <=2 closest rays,
 //                                              <=1 shadow ray, <=1 new shading frame (wave ballot + prefix-sum
-//                                              compaction, one atomic per wave and queue)
-//   k_trace_shadow  GenLight.cpp:10-69         any-hit -> visibility into the owning frame
+//                                              compaction, one atomic per workgroup and queue)
+//   k_trace_shadow  GenLight.cpp:10-69         any-hit -> visibility into the owning frame (+ _park / k_shadow_mesh with meshes)
 //   k_combine       MtlBlinn.cpp:117-137,343,431,470,511,539  folds finished frames into their parents, deepest
 //                                              wave step first (the per-level clamps forbid a running throughput)
 //   k_resolve       Main.cpp:170,220-230       in-order sample sum, /spp, gamma, Color24
+//   k_photon_*      Main.cpp:319-386, cyPhotonMap.h   caustic photon map: emission, and the k-NN gather in three passes
+//   k_tiles_*       (no counterpart)           multi-GPU framebuffer exchange: pack / unpack of a rank's tiles
 // The recursion of the reference becomes: ray kinds (continuations) + a tree of shading frames.
 // No CPU fallback: every entry point fails when there is no usable HIP device.
 #include <hip/hip_runtime.h>
