@@ -4,6 +4,8 @@ MtlBlinn.cpp:203-303,329-342.
 CPU: the oracle against the golden vectors of the reference built with -DUSE_PhotonMap (tests/golden/
 c5_caustics_photon.npz): emitted photons, kd-balanced array, k-NN irradiance estimates, radiance with the
 caustic term — all bit-exact.  GPU: the HIP emission / gather kernels against the oracle in keyed + device-math mode."""
+import os
+
 import numpy as np
 import pytest
 
@@ -140,3 +142,36 @@ def test_gpu_photon_map_vs_oracle(B, load_scene, O):
     assert same_bits(gi3, oi3) and same_bits(gd3, od3)
     with pytest.raises(B.BhrtError):
         sc2.photon_import(path + ".missing")
+
+
+@pytest.mark.gpu
+def test_gpu_photon_map_on_random_scenes(B, O, tmp_path):
+    """Seeded random scenes (tools/fuzz_parity.py; seeds whose scenes have a caustic path, so that the emission loop
+    ends): emission through nested groups and mesh instances, balance, gathers at two radii with random normals and
+    photon-mapped radiance, all bit for bit against the oracle.  (27 such scenes were run by hand.)"""
+    import shutil, sys
+    from conftest import ROOT, SCENES
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity
+    shutil.copy(os.path.join(SCENES, "mesh_small.obj"), tmp_path / "mesh_small.obj")
+    for seed in (10, 13, 17, 31, 44):
+        rng = np.random.default_rng(seed)
+        xml = str(tmp_path / f"f{seed}.xml")
+        fuzz_parity.random_scene(rng, xml)
+        sc = B.Scene(xml)
+        blob = sc.flat_bytes()
+        n = sc.photon_build(B.default_opts(seed=seed), 3000)
+        bal, _, _ = O.photon_build(blob, 3000, seed=seed)
+        assert n == len(bal) and np.array_equal(sc.photon_get(), bal), seed
+        q = np.random.default_rng(seed + 1)
+        pts = sc.photon_get()[:, :12].copy().view(np.float32).reshape(-1, 3)
+        p = (pts[q.integers(0, len(pts), 400)] + q.normal(scale=0.2, size=(400, 3))).astype(np.float32)
+        nr = q.normal(size=(400, 3)).astype(np.float32)
+        nr /= np.linalg.norm(nr, axis=1, keepdims=True)
+        for radius in (0.5, 3.0):
+            gi_, gd = sc.photon_gather(p, nr, radius)
+            oi, od = O.photon_gather(p, nr, radius)
+            assert same_bits(gi_, oi) and same_bits(gd, od), (seed, radius)
+        gs, _ = sc.render_samples(B.default_opts(spp=1, gi_bounces=1, seed=seed, photon_map=1), 0, 0, sc.width, sc.height)
+        rs = O.render(blob, sc.width, sc.height, 1, gi=1, seed=seed, region=(0, 0, sc.width, sc.height), photon=1)["samples"]
+        assert same_bits(gs, rs), seed

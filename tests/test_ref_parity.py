@@ -159,3 +159,42 @@ def test_random_scenes_reference_vs_oracle(B, O, tmp_path):
         o = O.render(sc.flat_bytes(), sc.width, sc.height, 2, gi=gi, seed=seed, rng=O.RNG_SEQUENTIAL, math=O.MATH_LIBM, region=(0, 0, 96, 72), threads=4)
         assert same_bits(o["samples"], np.fromfile(pre + ".samples_f32", np.float32).reshape(96 * 72, 2, 3)), seed
         assert np.array_equal(o["rgb8"].reshape(-1, 3), np.fromfile(pre + ".rgb8", np.uint8).reshape(-1, 3)), seed
+
+
+def test_random_scenes_photon_map_reference_vs_oracle(B, O, tmp_path):
+    """BuildCausticPhotonMap + PrepareForIrradianceEstimation of the unmodified reference (oracle/_ref/ref_harness_pm) on
+    seeded random scenes that have a caustic path: emitted and balanced photon bytes and the emission count equal the
+    oracle's (sequential / libm mode).  (34 such scenes were run by hand; scenes without a caustic path never leave the
+    reference's emission loop.)"""
+    import shutil, sys
+    from conftest import REF_HARNESS
+    harness_pm = REF_HARNESS + "_pm"
+    if not os.path.exists(harness_pm):
+        pytest.skip("oracle/_ref/ref_harness_pm not built")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity
+    shutil.copy(os.path.join(SCENES, "mesh_small.obj"), tmp_path / "mesh_small.obj")
+    for seed in (11, 14, 31, 40):
+        rng = np.random.default_rng(seed)
+        xml = f"f{seed}.xml"
+        fuzz_parity.random_scene(rng, str(tmp_path / xml))
+        pre = str(tmp_path / f"p{seed}")
+        subprocess.run([harness_pm, xml, pre, "--seed", str(seed), "--photons", "1500", "photons"], cwd=str(tmp_path), check=True, timeout=120,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        cwd = os.getcwd()
+        os.chdir(tmp_path)
+        try:
+            sc = B.Scene(xml)
+        finally:
+            os.chdir(cwd)
+        bal, emitted, n_emit = O.photon_build(sc.flat_bytes(), 1500, seed=seed, rng=O.RNG_SEQUENTIAL, math=O.MATH_LIBM)
+        meta = np.fromfile(pre + ".photons_meta", np.uint64)
+        assert n_emit == int(meta[1]), seed
+        ref_em = np.fromfile(pre + ".photons_emitted", np.uint8).reshape(-1, 24)
+        ref_bal = np.fromfile(pre + ".photons_balanced", np.uint8).reshape(-1, 24)
+        m = np.ones(24, bool)
+        m[19] = False   # byte 19 = planeAndDirZ: bit 3 always defined, the split-plane bits only for internal nodes (uninitialised elsewhere)
+        assert np.array_equal(emitted[:, m], ref_em[:, m]) and np.array_equal(emitted[:, 19] & 8, ref_em[:, 19] & 8), seed
+        assert np.array_equal(bal[:, m], ref_bal[:, m]) and np.array_equal(bal[:, 19] & 8, ref_bal[:, 19] & 8), seed
+        internal = np.arange(1, len(ref_bal) + 1) < int(meta[3])
+        assert np.array_equal(bal[internal, 19] & 3, ref_bal[internal, 19] & 3), seed
