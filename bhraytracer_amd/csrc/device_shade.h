@@ -266,38 +266,50 @@ __device__ inline V3 gi_direction(DRng &g, bool &useSpecular, V3 vN, V3 vV, floa
 }
 __device__ inline float tc_max(const float *c) { return fmax_cy(fmax_cy(c[0], c[1]), c[2]); } // GetKD/GetKS, MtlBlinn.cpp:68-69
 __device__ inline float gray3(const float *c) { return (c[0] + c[1] + c[2]) / 3.0f; }
-// GetSampleInLight, MtlBlinn.cpp:637-695
+// GetSampleInLight, MtlBlinn.cpp:637-695.  The reference builds both candidate directions (Phong lobe around L, disk of the
+// light) and keeps one.  Which one is kept depends only on scalars (the lobe angle, the disk radius, one more draw), so the
+// draws and scalars of both are evaluated in the reference's order and ONE direction is then constructed from the
+// selected (axis, x, y, crossing vector): the same operations on the kept candidate, ~200 instructions less per call.
 __device__ inline V3 sample_in_light(DRng &g, const float *diffuseColor, const float *specularColor, const bhrt_light &light, V3 hitP, float glossiness)
 {
     if (light.type == BHRT_LIGHT_POINT) {
         float kd = tc_max(diffuseColor), ks = tc_max(specularColor);
-        float p_diffuse = 0, p_specular = 0;
-        V3 diffuse_vL, specular_vL;
         V3 vL = ld3(light.vec) - hitP;
-        {
-            float diffuseTheta = 0;
-            diffuse_vL = sample_along_light_direction(g, normalized(vL), glossiness, diffuseTheta);
-            p_diffuse = dm::powf_(dm::cosf_(diffuseTheta), glossiness);
+        // ---- candidate 1: GetSampleAlongLightDirection(L normalised, glossiness) — draws u, phi, (crossing vector)
+        const V3 nL = normalized(vL);
+        const float u = g.rnd01();
+        const float diffuseTheta = acos_safe(dm::powf_(u, 1.f / (glossiness + 1.f)));
+        const float Rd = dm::tanf_(diffuseTheta);
+        const float phi_d = (float)(g.rnd01() * 2 * BHRT_PI_D);
+        const V3 rc_d = random_crossing_vector(g, nL);
+        const float p_diffuse = dm::powf_(dm::cosf_(diffuseTheta), glossiness);
+        bool useSpecular = false;
+        float Rs = 0, theta_s = 0;
+        V3 rc_s = v3(0, 0, 1);
+        if (!(ks == 0 && kd != 0)) {
+            // ---- candidate 2: point on the light's disk — draws r, theta, (crossing vector)
+            const float r = g.rnd01();
+            Rs = sqrtf(r) * (int)light.size; // GetSize() truncates to int (lights.h:76)
+            theta_s = (float)(g.rnd01() * 2 * BHRT_PI_D);
+            rc_s = random_crossing_vector(g, vL);
+            const float p_specular = 2 * r / (Rs * Rs);
+            if (ks != 0 && kd == 0) useSpecular = true;
+            else {
+                const float P_Diffuse = kd * p_diffuse;
+                const float P_Specular = ks * p_specular;
+                const float P_sum = P_Diffuse + P_Specular;
+                const float P_Diffuse_Norm = P_Diffuse / P_sum;
+                const float rnd = g.rnd01();
+                useSpecular = rnd >= P_Diffuse_Norm;
+            }
         }
-        if (ks == 0 && kd != 0) return normalized(diffuse_vL);
-        {
-            float r = g.rnd01();
-            float R = sqrtf(r) * (int)light.size; // GetSize() truncates to int (lights.h:76)
-            float specularTheta = (float)(g.rnd01() * 2 * BHRT_PI_D);
-            float x = R * dm::cosf_(specularTheta), y = R * dm::sinf_(specularTheta);
-            V3 axis1 = cross(random_crossing_vector(g, vL), vL);
-            V3 axis2 = cross(axis1, vL);
-            specular_vL = vL + normalized(axis1) * x + normalized(axis2) * y;
-            p_specular = 2 * r / (R * R);
-        }
-        if (ks != 0 && kd == 0) return normalized(specular_vL);
-        float P_Diffuse = kd * p_diffuse;
-        float P_Specular = ks * p_specular;
-        float P_sum = P_Diffuse + P_Specular;
-        float P_Diffuse_Norm = P_Diffuse / P_sum;
-        float rnd = g.rnd01();
-        bool useSpecular = rnd >= P_Diffuse_Norm;
-        return useSpecular ? normalized(specular_vL) : normalized(diffuse_vL);
+        // ---- the kept candidate: axis + unit(axis1) * x + unit(axis2) * y, normalised
+        const V3 axis = useSpecular ? vL : nL, rc = useSpecular ? rc_s : rc_d;
+        const float R = useSpecular ? Rs : Rd, ang = useSpecular ? theta_s : phi_d;
+        const float x = R * dm::cosf_(ang), y = R * dm::sinf_(ang);
+        const V3 axis1 = cross(rc, axis);
+        const V3 axis2 = cross(axis1, axis);
+        return normalized(axis + normalized(axis1) * x + normalized(axis2) * y);
     }
     V3 dd = light.type == BHRT_LIGHT_DIRECT ? ld3(light.vec) : v3(0, 0, 0);
     return -(normalized(dd));
