@@ -45,6 +45,34 @@ namespace bhrt {
 
 constexpr int kBlock = 256;
 
+// Exact unsigned 32-bit division by a divisor that is fixed for a launch (Granlund & Montgomery, "Division by invariant
+// integers using multiplication"): the slot -> (pixel, sample) -> tile arithmetic is four div/mod pairs per lane, ~20
+// instructions each as runtime divisions, 5 as this.  Holds for every 32-bit dividend.
+struct FastDiv {
+    uint32_t d, m, s1, s2;
+};
+static FastDiv MakeFastDiv(uint32_t d)
+{
+    FastDiv f;
+    f.d = d ? d : 1;
+    uint32_t l = 0;
+    while ((1ull << l) < f.d) l++; // ceil(log2 d)
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - f.d)) / f.d + 1);
+    f.s1 = l < 1 ? l : 1;
+    f.s2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+__device__ inline uint32_t fdiv(uint32_t n, const FastDiv &f)
+{
+    const uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+__device__ inline void fdivmod(uint32_t n, const FastDiv &f, uint32_t &q, uint32_t &r)
+{
+    q = fdiv(n, f);
+    r = n - q * f.d;
+}
+
 struct PassInfo {
     int32_t W, H, tile, tiles_x, tiles_y, rank, world;
     uint32_t q0;       // first owned-pixel index of this pass
@@ -55,6 +83,7 @@ struct PassInfo {
     // per-frame constants of RandomPositionInPixel (Main.cpp:132-139), formed once on the host with the same float
     // operations the reference performs per sample: unit dd_x, unit dd_y, |dd_x|
     float jx[3], jy[3], pixel_len;
+    FastDiv by_spp, by_tile_px, by_tiles_x, by_tile; // divisions by spp, tile * tile, tiles_x, tile
 };
 struct RenderParams {
     int32_t internal_bounces, gi_bounces;
@@ -65,12 +94,13 @@ struct RenderParams {
 // owned-pixel index q -> image coordinates; tiles are dealt round-robin to ranks
 __device__ inline bool pixel_of(const PassInfo &P, uint32_t q, int &i, int &j)
 {
-    const uint32_t tp = (uint32_t)(P.tile * P.tile);
-    const uint32_t k = q / tp, within = q % tp;
+    uint32_t k, within, ty, tx, wy, wx;
+    fdivmod(q, P.by_tile_px, k, within);
     const uint32_t tile_id = (uint32_t)P.rank + k * (uint32_t)P.world;
-    const uint32_t ty = tile_id / (uint32_t)P.tiles_x, tx = tile_id % (uint32_t)P.tiles_x;
-    i = (int)(tx * P.tile + within % P.tile);
-    j = (int)(ty * P.tile + within / P.tile);
+    fdivmod(tile_id, P.by_tiles_x, ty, tx);
+    fdivmod(within, P.by_tile, wy, wx);
+    i = (int)(tx * P.tile + wx);
+    j = (int)(ty * P.tile + wy);
     return ty < (uint32_t)P.tiles_y && i < P.W && j < P.H;
 }
 
@@ -124,7 +154,12 @@ __device__ inline void block_alloc3(BlockAllocLds &L, uint32_t *c0, uint32_t n0a
 }
 
 // per-sample radiance buffer is sample-major: [sample][pixel of the pass] -> k_resolve reads coalesced
-__device__ inline uint32_t sample_addr(const PassInfo &P, uint32_t slot) { return (slot % (uint32_t)P.spp) * P.n_pixels + slot / (uint32_t)P.spp; }
+__device__ inline uint32_t sample_addr(const PassInfo &P, uint32_t slot)
+{
+    uint32_t px, smp;
+    fdivmod(slot, P.by_spp, px, smp);
+    return smp * P.n_pixels + px;
+}
 
 __device__ inline void put_ray(const RayQueue &q, uint32_t i, V3 o, V3 d, uint32_t frame, uint32_t meta, uint32_t ctr)
 {
@@ -144,7 +179,8 @@ __device__ inline V3 ld3i(const float *a, uint32_t i) { return v3(a[3 * (size_t)
 __device__ inline bool camera_ray(const DevScene &S, const PassInfo &P, uint32_t idx, V3 &o, V3 &d)
 {
     int i = 0, j = 0;
-    const uint32_t q_local = idx / (uint32_t)P.spp, s = idx % (uint32_t)P.spp;
+    uint32_t q_local, s;
+    fdivmod(idx, P.by_spp, q_local, s);
     o = v3(0, 0, 0); d = v3(0, 0, 0);
     if (!pixel_of(P, P.q0 + q_local, i, j)) return false;
     // PathTracing(), Main.cpp:145: pixel "centre" = corner because 1/2 == 0
@@ -605,8 +641,10 @@ __global__ void __launch_bounds__(kShadeBlock, BHRT_SHADE_WAVES) k_shade(DevScen
         V3 mult = v3(1, 1, 1);
         if (kind == RK_CAMERA) {
             int pi, pj;
-            pixel_of(P, P.q0 + owner / (uint32_t)P.spp, pi, pj);
-            skey = bhrt_sample_key(P.seed, (uint32_t)(pj * P.W + pi), owner % (uint32_t)P.spp);
+            uint32_t opx, osmp;
+            fdivmod(owner, P.by_spp, opx, osmp);
+            pixel_of(P, P.q0 + opx, pi, pj);
+            skey = bhrt_sample_key(P.seed, (uint32_t)(pj * P.W + pi), osmp);
             gi = R.gi_bounces;
             bounce = R.internal_bounces;
             how = FH_ROOT;
@@ -647,7 +685,7 @@ __global__ void __launch_bounds__(kShadeBlock, BHRT_SHADE_WAVES) k_shade(DevScen
         if (kind == RK_CAMERA) {
             // background.Sample((i/W, j/H, 0)), Main.cpp:166-167
             int pi, pj;
-            pixel_of(P, P.q0 + owner / (uint32_t)P.spp, pi, pj);
+            pixel_of(P, P.q0 + fdiv(owner, P.by_spp), pi, pj);
             st3(samples, sample_addr(P, owner), kTex ? tc_sample(S, S.background, v3((float)pi / S.cam.width, (float)pj / S.cam.height, 0.0f)) : ld3(S.background.color));
         } else if (kind == RK_GI) {
             V3 mult = ld3i(F.gi_mult, owner);
@@ -1394,6 +1432,8 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
     PassInfo P;
     P.W = W; P.H = Hh; P.tile = tile; P.tiles_x = (W + tile - 1) / tile; P.tiles_y = (Hh + tile - 1) / tile;
     P.rank = o.rank; P.world = world; P.spp = o.spp; P.seed = o.seed; P.jitter = o.jitter; P.gamma = o.gamma;
+    P.by_spp = MakeFastDiv((uint32_t)o.spp); P.by_tile_px = MakeFastDiv((uint32_t)(tile * tile)); P.by_tiles_x = MakeFastDiv((uint32_t)P.tiles_x);
+    P.by_tile = MakeFastDiv((uint32_t)tile);
     {
         const V3 ddx = v3(H->camera.dd_x[0], H->camera.dd_x[1], H->camera.dd_x[2]), ddy = v3(H->camera.dd_y[0], H->camera.dd_y[1], H->camera.dd_y[2]);
         const V3 ux = normalized(ddx), uy = normalized(ddy); // IEEE sqrt and divisions, no contraction: the bits the kernels used to compute per sample
