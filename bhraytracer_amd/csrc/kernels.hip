@@ -514,6 +514,13 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
     }
     // ---- global illumination, PathTracing_GlobalIllumination (MtlBlinn.cpp:383-433)
     const bool textured = kTex && (m.diffuse.map >= 0 || newSpecular.map >= 0);
+    // diffuse.Sample(uvw, duvw) / specular.Sample(uvw, duvw): the reference evaluates them again at every use (GI multiplier,
+    // direct term, caustic term) with the same arguments — 32 filter taps each; once is enough
+    V3 kd_s = ld3(m.diffuse.color), ks_s = ld3(newSpecular.color);
+    if (textured) {
+        kd_s = tc_sample_d(S, m.diffuse, a.uvw, a.du, a.dv);
+        ks_s = tc_sample_d(S, newSpecular, a.uvw, a.du, a.dv);
+    }
     if (gi >= 0) {
         DRng g;
         g.key = bhrt_section_key(skey, code, BHRT_SEC_GI);
@@ -524,7 +531,7 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
         out.has_gi = true;
         flags |= FF_HAS_GI;
         const bhrt_texcolor &tcs = useSpecular ? newSpecular : m.diffuse;
-        st3(F.gi_mult, f, textured ? tc_sample_d(S, tcs, a.uvw, a.du, a.dv) : ld3(tcs.color));
+        st3(F.gi_mult, f, useSpecular ? ks_s : kd_s);
     }
     // ---- direct light, PathTracing_DiffuseNSpecular (MtlBlinn.cpp:304-351)
     if (S.n_lights > 0) {
@@ -560,15 +567,14 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
                     out.stmax = 1;
                 }
             }
-            V3 kd = textured ? tc_sample_d(S, m.diffuse, a.uvw, a.du, a.dv) : ld3(m.diffuse.color);
-            V3 ks = textured ? tc_sample_d(S, newSpecular, a.uvw, a.du, a.dv) : ld3(newSpecular.color);
+            const V3 kd = kd_s, ks = ks_s;
             st3(F.brdf, f, kd * cosTheta + ks * dm::powf_(dot(vH, vN), m.glossiness));
         }
     }
     if (R.photon) { // inputs of the caustic term (MtlBlinn.cpp:329-342), evaluated by k_photon_gather_frames
         st3(F.ph_p, f, a.p); st3(F.ph_n, f, a.N); st3(F.ph_v, f, vV);
-        st3(F.ph_kd, f, textured ? tc_sample_d(S, m.diffuse, a.uvw, a.du, a.dv) : ld3(m.diffuse.color));
-        st3(F.ph_ks, f, textured ? tc_sample_d(S, newSpecular, a.uvw, a.du, a.dv) : ld3(newSpecular.color));
+        st3(F.ph_kd, f, kd_s);
+        st3(F.ph_ks, f, ks_s);
     }
     F.info[f] = how | (dmode << 3) | (light_idx << 8) | (flags << 16) | ((uint32_t)(mi & 0xfff) << 20); // the frame's only write of info
 }
