@@ -190,6 +190,23 @@ __device__ inline NodeRec node_at(const MeshRef &M, uint32_t i)
     }
     return n;
 }
+// the two children of an inner node (adjacent, first id even): both in the LDS nodelet or both in global memory
+// (BHRT_LDS_NODES is even), so one branch and four 16-byte loads fetch the pair
+__device__ inline void node_pair_at(const MeshRef &M, uint32_t c1, NodeRec &n1, NodeRec &n2)
+{
+    float4 a, b, c, d;
+    if (c1 < M.n_lds) {
+        const float4 *p = (const float4 *)(M.lds + c1);
+        a = p[0]; b = p[1]; c = p[2]; d = p[3];
+    } else {
+        const float4 *p = (const float4 *)(M.bvh + c1);
+        a = p[0]; b = p[1]; c = p[2]; d = p[3];
+    }
+    n1.b[0] = a.x; n1.b[1] = a.y; n1.b[2] = a.z; n1.b[3] = a.w; n1.b[4] = b.x; n1.b[5] = b.y;
+    n1.data = __float_as_uint(b.z); n1.parent = __float_as_uint(b.w);
+    n2.b[0] = c.x; n2.b[1] = c.y; n2.b[2] = c.z; n2.b[3] = c.w; n2.b[4] = d.x; n2.b[5] = d.y;
+    n2.data = __float_as_uint(d.z); n2.parent = __float_as_uint(d.w);
+}
 __device__ inline uint32_t node_parent(const MeshRef &M, uint32_t i) { return i < M.n_lds ? M.lds[i].parent : M.bvh[i].parent; }
 __device__ inline uint32_t node_data(const MeshRef &M, uint32_t i) { return i < M.n_lds ? M.lds[i].data : M.bvh[i].data; }
 
@@ -224,7 +241,8 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
         while (desc && !(data & 0x80000000u)) {
             const uint32_t c1 = data & 0x7fffffffu;
             float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
-            const NodeRec n1 = node_at(M, c1), n2 = node_at(M, c1 + 1);
+            NodeRec n1, n2;
+            node_pair_at(M, c1, n1, n2);
             const uint32_t d1 = n1.data, d2 = n2.data;
             bool b1 = box_hit_rcp(n1.b, o, d, rr, ht, tmin1);
             bool b2 = box_hit_rcp(n2.b, o, d, rr, ht, tmin2);
