@@ -391,7 +391,9 @@ __device__ inline bool plane_hit(V3 p, V3 d, int side, float t_cur, float &t_out
 // LDS nodelet: the workgroup copies the first BHRT_LDS_NODES nodes (top levels, breadth-first numbering) of the mesh it is
 // about to traverse into LDS.  Uniform control flow is required (every thread of the block reaches the barriers): the
 // scene-graph loop below is uniform — `active` only predicates the per-ray work.
+#ifndef BHRT_LDS_NODES
 #define BHRT_LDS_NODES 512 /* 16 KB per workgroup: 9 full levels */
+#endif
 __device__ inline void stage_nodelet(const DevScene &S, int mesh, bhrt_bvh_node *lds, MeshRef &M)
 {
     M = mesh_ref(S, mesh);
