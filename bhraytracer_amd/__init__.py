@@ -64,7 +64,7 @@ EXPORTS = [
     "bhrt_scene_warning", "bhrt_scene_flat", "bhrt_scene_upload", "bhrt_device_count",
     "bhrt_trace_closest_host", "bhrt_trace_closest_dev", "bhrt_trace_shadow_host", "bhrt_trace_shadow_dev",
     "bhrt_render", "bhrt_render_dev", "bhrt_render_samples", "bhrt_photon_build", "bhrt_photon_gather_host",
-    "bhrt_photon_get", "bhrt_photon_export", "bhrt_photon_import", "bhrt_save_png", "bhrt_math_eval_dev",
+    "bhrt_photon_get", "bhrt_photon_export", "bhrt_photon_import", "bhrt_photon_build_global", "bhrt_save_png", "bhrt_math_eval_dev",
     "bhrt_tiles_block_bytes", "bhrt_tiles_pack_dev", "bhrt_tiles_unpack_dev",
 ]
 
@@ -228,6 +228,14 @@ class Scene:
         d = np.zeros_like(p)
         _check(lib().bhrt_photon_gather_host(self._h, _ptr(p), _ptr(nrm), C.c_size_t(p.shape[0]), C.c_float(radius), _ptr(irr), _ptr(d)))
         return irr, d
+
+    def photon_build_global(self, opts: Opts, max_photons: int, dat_path=None) -> np.ndarray:
+        """BuildPhotonMap (Main.cpp:251-295): the global photon map, balanced (n, 24) uint8 records."""
+        out = np.zeros((max_photons, 24), np.uint8)
+        n = C.c_uint32(0)
+        _check(lib().bhrt_photon_build_global(self._h, C.byref(opts), int(max_photons), _ptr(out), int(max_photons), C.byref(n),
+                                              os.fsencode(dat_path) if dat_path else None))
+        return out[: n.value].copy()
 
     def photon_export(self, path: str):
         _check(lib().bhrt_photon_export(self._h, os.fsencode(path)))

@@ -111,6 +111,10 @@ __device__ inline bool refraction_out(DRng &g, V3 inDir, V3 hitP, V3 hitN, float
 
 // One emitted photon followed to its end.  Writes at most `cap` records to out[0..), returns how many the
 // reference would have passed to AddPhoton (may exceed cap -> caller flags overflow).
+// kGlobal = false: the caustic map (TraceCausticPhotonRay + RandomPhotonBounceForCaustic, Main.cpp:319-340, MtlBlinn.cpp:203-303);
+// kGlobal = true: the global map (TracePhotonRay + RandomPhotonBounce, Main.cpp:296-317, MtlBlinn.cpp:140-202): a transmissive
+// surface ends the photon, a diffuse bounce continues it with the power rescaled by kd / p_Diff.
+template <bool kGlobal>
 __device__ inline uint32_t emit_photon_path(const DevScene &S, uint32_t seed, uint64_t emission, const int32_t *plights, int n_plights,
                                             float sum_intensity, DPhoton *out, uint32_t cap)
 {
@@ -150,6 +154,7 @@ __device__ inline uint32_t emit_photon_path(const DevScene &S, uint32_t seed, ui
         V3 vN = normalized(a.N);
         V3 vV = -(normalized(d));
         if (gray3(m.refraction.color) > 0) {
+            if (kGlobal) break; // RandomPhotonBounce returns false for a transmissive material (MtlBlinn.cpp:149-151)
             float cosPhi1 = dot(vN, vV);
             float sinPhi1 = sqrtf(1 - cosPhi1 * cosPhi1);
             float sinPhi2 = sinPhi1 / m.ior;
@@ -171,7 +176,7 @@ __device__ inline uint32_t emit_photon_path(const DevScene &S, uint32_t seed, ui
         } else {
             if (r01 < BHRT_PHOTON_ABSORB) break;
             float diffuseTheta = 0;
-            (void)normalized(sample_in_semi_sphere(g, vN, diffuseTheta));
+            const V3 diffuseRayDir = normalized(sample_in_semi_sphere(g, vN, diffuseTheta));
             float p_diffuseTheta = dm::sinf_(2 * diffuseTheta);
             float specularTheta = 0;
             float cosvVvN = dot(vN, vV);
@@ -182,9 +187,16 @@ __device__ inline uint32_t emit_photon_path(const DevScene &S, uint32_t seed, ui
             float P_sum = P_Diffuse + tc_max(m.specular.color) * p_specularTheta;
             float p_Diff = (P_Diffuse / P_sum) * (1 - BHRT_PHOTON_ABSORB) + BHRT_PHOTON_ABSORB;
             float p_Spec = (1 - p_Diff) * (1 - BHRT_PHOTON_ABSORB) + BHRT_PHOTON_ABSORB;
-            if (!(r01 >= p_Diff)) break; // diffuse bounce: a caustic photon stops
-            intensity = intensity * (ld3(m.specular.color) / p_Spec);
-            d = specRayDir;
+            const bool useSpecular = r01 >= p_Diff;
+            if (!kGlobal && !useSpecular) break; // diffuse bounce: a caustic photon stops
+            if (kGlobal) {
+                const V3 kdf = ld3(m.diffuse.color) / p_Diff, ksf = ld3(m.specular.color) / p_Spec;
+                intensity = intensity * (useSpecular ? ksf : kdf);
+                d = useSpecular ? specRayDir : diffuseRayDir;
+            } else {
+                intensity = intensity * (ld3(m.specular.color) / p_Spec);
+                d = specRayDir;
+            }
             o = a.p + a.N * BHRT_BIAS;
         }
         first = false;

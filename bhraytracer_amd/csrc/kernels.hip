@@ -892,12 +892,13 @@ __global__ void k_copy_samples(PassInfo P, const float *samples, int x0, int y0,
 
 // ------------------------------------------------------------------------------------------------
 // photon map kernels
+template <bool kGlobal>
 __global__ void __launch_bounds__(kBlock) k_photon_emit(DevScene S, uint32_t seed, uint64_t e0, uint32_t E, const int32_t *plights, int n_plights,
                                                          float sum_intensity, DPhoton *tmp, uint32_t cap, uint32_t *counts)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E) return;
-    counts[i] = emit_photon_path(S, seed, e0 + i, plights, n_plights, sum_intensity, tmp + (size_t)i * cap, cap);
+    counts[i] = emit_photon_path<kGlobal>(S, seed, e0 + i, plights, n_plights, sum_intensity, tmp + (size_t)i * cap, cap);
 }
 // stable compaction in emission order: path i's photons go to out[1 + offsets[i] + k] (slot 0 stays unused)
 __global__ void __launch_bounds__(kBlock) k_photon_compact(const DPhoton *tmp, uint32_t cap, const uint32_t *counts, const uint32_t *offsets, uint32_t E,
@@ -1905,7 +1906,9 @@ static int InstallPhotonMap(DeviceState *D)
     return BHRT_OK;
 }
 
-int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, uint32_t *n_stored)
+// Emission + stable compaction + ScalePhotonPowers + balance; `out` = the balanced records (slot 0 unused).
+// global_map: BuildPhotonMap / TracePhotonRay / RandomPhotonBounce instead of the caustic variants.
+static int BuildPhotons(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, bool global_map, std::vector<HostPhoton> &out)
 {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
@@ -1923,14 +1926,13 @@ int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_pho
     float sum = 0;
     for (int32_t i : pl) sum += key(i);
 
-    if (D->d_photons) { (void)hipFree(D->d_photons); D->d_photons = nullptr; D->n_photons = 0; }
     DPhoton *d_out = nullptr, *d_tmp = nullptr;
     uint32_t *d_counts = nullptr, *d_offsets = nullptr;
     int32_t *d_pl = nullptr;
     auto cleanup = [&]() { if (d_tmp) (void)hipFree(d_tmp); if (d_counts) (void)hipFree(d_counts); if (d_offsets) (void)hipFree(d_offsets); if (d_pl) (void)hipFree(d_pl); };
     HIP_CHECK(hipMalloc(&d_out, ((size_t)max_photons + 1) * sizeof(DPhoton)));
     HIP_CHECK(hipMemset(d_out, 0, ((size_t)max_photons + 1) * sizeof(DPhoton)));
-    const uint32_t E = 1u << 20; // emissions per batch
+    const uint32_t E = global_map ? 1u << 16 : 1u << 20; // emissions per batch (nearly every emission of the global map stores photons)
     uint32_t cap = 8;            // photons one path may store before the batch is redone with more room
     HIP_CHECK(hipMalloc(&d_counts, E * sizeof(uint32_t)));
     HIP_CHECK(hipMalloc(&d_offsets, E * sizeof(uint32_t)));
@@ -1941,7 +1943,8 @@ int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_pho
     uint64_t e0 = 0, stored = 0;
     const uint64_t emission_budget = (uint64_t)max_photons * 4096ull + (1ull << 24);
     while (stored < max_photons && e0 < emission_budget) {
-        hipLaunchKernelGGL(k_photon_emit, dim3(E / kBlock), dim3(kBlock), 0, D->stream, D->S, opts->seed, e0, E, d_pl, (int)pl.size(), sum, d_tmp, cap, d_counts);
+        if (global_map) hipLaunchKernelGGL(k_photon_emit<true>, dim3(E / kBlock), dim3(kBlock), 0, D->stream, D->S, opts->seed, e0, E, d_pl, (int)pl.size(), sum, d_tmp, cap, d_counts);
+        else hipLaunchKernelGGL(k_photon_emit<false>, dim3(E / kBlock), dim3(kBlock), 0, D->stream, D->S, opts->seed, e0, E, d_pl, (int)pl.size(), sum, d_tmp, cap, d_counts);
         HIP_CHECK(hipMemcpyAsync(counts.data(), d_counts, E * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
         HIP_CHECK(hipStreamSynchronize(D->stream));
         uint32_t maxc = 0;
@@ -1966,17 +1969,52 @@ int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_pho
     if (n == 0) { (void)hipFree(d_out); SetError("photon map: no photon reached a photon surface"); return BHRT_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_photon_scale, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, d_out, n, 1.f / (float)(int)n); // Main.cpp:380
     // PrepareForIrradianceEstimation on the host (cyPhotonMap.h:236-258), then back to HBM
-    D->h_photons.assign((size_t)n + 1, HostPhoton());
-    HIP_CHECK(hipMemcpyAsync(D->h_photons.data(), d_out, ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyDeviceToHost, D->stream));
+    out.assign((size_t)n + 1, HostPhoton());
+    HIP_CHECK(hipMemcpyAsync(out.data(), d_out, ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyDeviceToHost, D->stream));
     HIP_CHECK(hipStreamSynchronize(D->stream));
     (void)hipFree(d_out);
-    memset(&D->h_photons[0], 0, sizeof(HostPhoton));
-    BalancePhotons(D->h_photons);
-    rc = InstallPhotonMap(D);
-    if (rc) return rc;
-    if (n_stored) *n_stored = n;
+    memset(&out[0], 0, sizeof(HostPhoton));
+    BalancePhotons(out);
     return BHRT_OK;
 }
+
+int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, uint32_t *n_stored)
+{
+    if (!scene) { SetError("null scene"); return BHRT_ERR_ARG; }
+    std::vector<HostPhoton> balanced;
+    int rc = BuildPhotons(scene, opts, max_photons, false, balanced);
+    if (rc) return rc;
+    DeviceState *D = scene->dev;
+    D->h_photons.swap(balanced);
+    rc = InstallPhotonMap(D);
+    if (rc) return rc;
+    if (n_stored) *n_stored = D->n_photons;
+    return BHRT_OK;
+}
+
+int bhrt_photon_build_global(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, void *photons_out, uint32_t capacity, uint32_t *n_stored,
+                             const char *dat_path)
+{
+    if (!scene) { SetError("null scene"); return BHRT_ERR_ARG; }
+    std::vector<HostPhoton> balanced;
+    int rc = BuildPhotons(scene, opts, max_photons, true, balanced);
+    if (rc) return rc;
+    const uint32_t n = (uint32_t)balanced.size() - 1;
+    if (n_stored) *n_stored = n;
+    if (photons_out) {
+        if (capacity < n) { SetError("photon buffer too small"); return BHRT_ERR_ARG; }
+        memcpy(photons_out, &balanced[1], (size_t)n * sizeof(HostPhoton));
+    }
+    if (dat_path) { // Resource/photonmap.dat, Main.cpp:292-294
+        FILE *fp = fopen(dat_path, "wb");
+        if (!fp) { SetError(std::string("cannot write ") + dat_path); return BHRT_ERR_IO; }
+        const bool ok = fwrite(&balanced[1], sizeof(HostPhoton), n, fp) == n;
+        fclose(fp);
+        if (!ok) { SetError("short write"); return BHRT_ERR_IO; }
+    }
+    return BHRT_OK;
+}
+
 
 int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *nrm, size_t cnt, float radius, float *irrad, float *dir)
 {

@@ -125,6 +125,12 @@ int bhrt_render_samples(bhrt_scene *scene, const bhrt_opts *opts, int x0, int y0
 
 /* ---- caustic photon map (Main.cpp:342-386, DataStructure/cyPhotonMap.h) -------------------------- */
 int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, uint32_t *n_stored);
+/* The reference's second map, BuildPhotonMap (Main.cpp:251-295; TracePhotonRay Main.cpp:296-317, RandomPhotonBounce
+ * MtlBlinn.cpp:140-202): photons that survive diffuse and specular bounces.  Its only call is commented out in the reference
+ * (Main.cpp:196) and nothing gathers from it, so it is built on request and handed back: balanced 24-byte records into
+ * photons_out (capacity records; may be NULL) and / or written like Resource/photonmap.dat (dat_path, may be NULL). */
+int bhrt_photon_build_global(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, void *photons_out, uint32_t capacity, uint32_t *n_stored,
+                             const char *dat_path);
 int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *n, size_t cnt, float radius, float *irrad, float *dir);
 int bhrt_photon_get(const bhrt_scene *scene, void *photons_out /* 24 B records, balanced order */, uint32_t capacity, uint32_t *n);
 int bhrt_photon_export(const bhrt_scene *scene, const char *dat_path); /* 24-byte records, Main.cpp:383-385 */

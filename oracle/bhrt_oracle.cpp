@@ -1522,6 +1522,7 @@ template <class M> struct PhotonTracer {
     Shader<M> sh;
     PhotonMapView &pm;
     int maxPhotons;
+    bool global_map = false; // false: caustic map (BuildCausticPhotonMap); true: global map (BuildPhotonMap, Main.cpp:251-317)
     PhotonTracer(const Scene &s, PhotonMapView &p, int maxp) : S(s), T(s, nullptr), X(s), sh(s, T, X, rng, nullptr, false), pm(p), maxPhotons(maxp) {}
 
     bool AddPhoton(const Vec3 &pos, const Vec3 &dir, const Color &power) // cyPhotonMap.h:218-232
@@ -1588,7 +1589,37 @@ template <class M> struct PhotonTracer {
         r.p = hInfo.p + hInfo.N * O_BIAS;
         return true;
     }
-    // TraceCausticPhotonRay, Main.cpp:319-340 (tail recursion -> loop)
+    // MtlBlinn::RandomPhotonBounce, MtlBlinn.cpp:140-202 (global map): a transmissive surface ends the photon, otherwise
+    // absorb / diffuse / specular roulette with the power rescaled by the chosen lobe's probability
+    bool Bounce(const bhrt_material &m, Ray &r, Color &c, const HitInfo &hInfo)
+    {
+        float rnd = rng.Rnd01();
+        Vec3 vN = hInfo.N.GetNormalized();
+        Vec3 vV = -(r.dir.GetNormalized());
+        Color refrC(m.refraction.color[0], m.refraction.color[1], m.refraction.color[2]);
+        if (refrC.Gray() > 0) return false;
+        if (rnd < 0.3f) return false; // Photon_AbsorbChance, MtlBlinn.cpp:27
+        float diffuseTheta = 0;
+        Vec3 diffuseRayDir = sh.GetSampleInSemiSphere(vN, diffuseTheta).GetNormalized();
+        float p_diffuseTheta = M::Sin(2 * diffuseTheta);
+        float specularTheta = 0;
+        float cosvVvN = vN.Dot(vV);
+        Vec3 vR = 2 * cosvVvN * vN - vV;
+        Vec3 specRayDir = sh.GetSampleAlongLightDirection(vR, m.glossiness, specularTheta);
+        float p_specularTheta = M::Pow(M::Cos(specularTheta), m.glossiness);
+        float P_Diffuse = Shader<M>::GetK(m.diffuse) * p_diffuseTheta;
+        float P_sum = P_Diffuse + Shader<M>::GetK(m.specular) * p_specularTheta;
+        float p_Diff = (P_Diffuse / P_sum) * (1 - 0.3f) + 0.3f;
+        float p_Spec = (1 - p_Diff) * (1 - 0.3f) + 0.3f;
+        bool useSpecular = rnd >= p_Diff;
+        Color kdf = Color(m.diffuse.color[0], m.diffuse.color[1], m.diffuse.color[2]) / p_Diff;
+        Color ksf = Color(m.specular.color[0], m.specular.color[1], m.specular.color[2]) / p_Spec;
+        c = c * (useSpecular ? ksf : kdf);
+        r.dir = useSpecular ? specRayDir : diffuseRayDir;
+        r.p = hInfo.p + hInfo.N * O_BIAS;
+        return true;
+    }
+    // TraceCausticPhotonRay / TracePhotonRay, Main.cpp:296-340 (tail recursion -> loop)
     void TracePhoton(Ray ray, Color intensity)
     {
         bool first = true;
@@ -1605,7 +1636,7 @@ template <class M> struct PhotonTracer {
             if (m.kind != BHRT_MTL_BLINN) return; // MultiMtl has no caustic bounce (scene.h:298)
             Ray nr = ray;
             Color ni = intensity;
-            if (!BounceForCaustic(m, nr, ni, h)) return;
+            if (!(global_map ? Bounce(m, nr, ni, h) : BounceForCaustic(m, nr, ni, h))) return;
             ray = nr;
             intensity = ni;
             first = false;
@@ -1676,6 +1707,34 @@ extern "C" int oracle_photon_build(const void *blob, const oracle_opts *opts, ui
     if (n_stored) *n_stored = (uint32_t)pm.numStored;
     if (n_emitted) *n_emitted = emitted;
     g_photon_map = &pm;
+    return 0;
+}
+
+// BuildPhotonMap (global map; nothing in the reference gathers from it, so it is not attached): balanced records and the
+// records in emission order (after ScalePhotonPowers) out
+extern "C" int oracle_photon_build_global(const void *blob, const oracle_opts *opts, uint32_t max_photons, void *photons_out, void *emitted_out,
+                                          uint32_t *n_stored, uint64_t *n_emitted)
+{
+    Scene S;
+    if (!S.Init(blob)) return 1;
+    static PhotonMapView gm;
+    gm = PhotonMapView();
+    gm.photons.assign((size_t)max_photons + 1, Photon());
+    memset(gm.photons.data(), 0, sizeof(Photon) * gm.photons.size());
+    gm.numStored = 0;
+    uint64_t emitted = 0;
+    if (opts->math_mode == ORACLE_MATH_DEVICE) { PhotonTracer<MathDevice> t(S, gm, (int)max_photons); t.global_map = true; emitted = t.Build(opts->seed, opts->rng_mode == ORACLE_RNG_KEYED); }
+    else { PhotonTracer<MathLibm> t(S, gm, (int)max_photons); t.global_map = true; emitted = t.Build(opts->seed, opts->rng_mode == ORACLE_RNG_KEYED); }
+    if (gm.numStored > 0) {
+        const float scale = 1.f / gm.numStored;
+        for (int i = 1; i <= gm.numStored; i++) gm.photons[i].power *= scale;
+    }
+    gm.photons.resize((size_t)gm.numStored + 1);
+    if (emitted_out && gm.numStored) memcpy(emitted_out, &gm.photons[1], sizeof(Photon) * gm.numStored);
+    PreparePhotonMap(gm);
+    if (photons_out && gm.numStored) memcpy(photons_out, &gm.photons[1], sizeof(Photon) * gm.numStored);
+    if (n_stored) *n_stored = (uint32_t)gm.numStored;
+    if (n_emitted) *n_emitted = emitted;
     return 0;
 }
 

@@ -67,6 +67,9 @@ int oracle_math_eval(int fn, int math_mode, const float *a, const float *b, size
 /* caustic photon map (Main.cpp:342-386, cyPhotonMap.h) — see bhrt_oracle.cpp */
 int oracle_photon_build(const void *blob, const oracle_opts *opts, uint32_t max_photons, void *photons_out /* 24 B each */,
                         uint32_t *n_stored, uint64_t *n_emitted);
+/* global photon map, BuildPhotonMap (Main.cpp:251-317, MtlBlinn.cpp:140-202): balanced + emission-order records (24 B each) */
+int oracle_photon_build_global(const void *blob, const oracle_opts *opts, uint32_t max_photons, void *photons_out, void *emitted_out,
+                               uint32_t *n_stored, uint64_t *n_emitted);
 int oracle_photon_unbalanced(void *out);                     /* the same photons in emission order (n_stored records) */
 int oracle_photon_attach(const void *photons, uint32_t n);  /* n balanced (heap-order) records, e.g. from the HIP path */
 int oracle_photon_balance(const void *emitted, uint32_t n, void *balanced_out); /* PrepareForIrradianceEstimation on n records */

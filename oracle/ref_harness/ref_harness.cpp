@@ -284,6 +284,36 @@ static bool BuildCausticPhotonMapN(int maxPhotons)
     causticPhotonMap->PrepareForIrradianceEstimation();
     return true;
 }
+// BuildPhotonMap (Main.cpp:251-295) restated the same way for the GLOBAL photon map: the loop body, TracePhotonRay and
+// RandomPhotonBounce are the reference's own (Main.cpp:296-317, MtlBlinn.cpp:140-202).
+static bool BuildPhotonMapN(int maxPhotons)
+{
+    photonMap = new PhotonMap();
+    photonMap->Resize(maxPhotons);
+    memset((void *)&photonMap->photons[0], 0, sizeof(cyPhotonMap::Photon) * (maxPhotons + 1));
+    std::vector<PointLight *> pointLightList;
+    for (auto it = lights.begin(); it != lights.end(); ++it)
+        if (PointLight *ptr = reinterpret_cast<PointLight *>(*it)) pointLightList.push_back(ptr);
+    if (pointLightList.size() == 0) return false;
+    sort(pointLightList.begin(), pointLightList.end(), ComparePointLight);
+    float sumOfPointLight = 0;
+    for (int i = 0; i < pointLightList.size(); ++i) sumOfPointLight += pointLightList[i]->GetIntensity() * pointLightList[i]->GetSize();
+    g_emitted = 0;
+    while (photonMap->NumPhotons() < maxPhotons) {
+        float rnd = Rnd01();
+        int i = 0;
+        while (rnd > pointLightList[i]->GetProbability(sumOfPointLight) && i < pointLightList.size() - 1) i++;
+        PointLight *thisLight = pointLightList[i];
+        Ray ray = thisLight->RandomPhoton();
+        Color bounceIntensity = thisLight->GetPhotonIntensity();
+        TracePhotonRay(ray, bounceIntensity, true);
+        g_emitted++;
+    }
+    photonMap->ScalePhotonPowers(1.f / photonMap->NumPhotons());
+    g_unbalanced.assign((unsigned char *)photonMap->GetPhotons(), (unsigned char *)photonMap->GetPhotons() + sizeof(cyPhotonMap::Photon) * maxPhotons);
+    photonMap->PrepareForIrradianceEstimation();
+    return true;
+}
 #endif
 
 static void usage()
@@ -381,6 +411,15 @@ int main(int argc, char **argv)
             WriteFile(prefix + ".photons_balanced", bal);
             std::vector<unsigned long long> meta = {(unsigned long long)causticPhotonMap->NumPhotons(), g_emitted, (unsigned long long)g_ctr, (unsigned long long)(long long)causticPhotonMap->halfStoredPhotons};
             WriteFile(prefix + ".photons_meta", meta);
+        } else if (cmd == "gphotons") { // the global photon map (BuildPhotonMap), same stream convention
+            g_key = bhrt_sample_key(seed, 0xFFFFFFFFu, 0x50484F54u);
+            g_ctr = 0;
+            if (!BuildPhotonMapN(nPhotons)) { fprintf(stderr, "no point light\n"); return 3; }
+            std::vector<unsigned char> bal((unsigned char *)photonMap->GetPhotons(), (unsigned char *)photonMap->GetPhotons() + sizeof(cyPhotonMap::Photon) * nPhotons);
+            WriteFile(prefix + ".gphotons_emitted", g_unbalanced);
+            WriteFile(prefix + ".gphotons_balanced", bal);
+            std::vector<unsigned long long> meta = {(unsigned long long)photonMap->NumPhotons(), g_emitted, (unsigned long long)g_ctr, (unsigned long long)(long long)photonMap->halfStoredPhotons};
+            WriteFile(prefix + ".gphotons_meta", meta);
         } else if (cmd == "gather") {
             std::vector<float> in = ReadFile<float>(gatherFile); // N x 6: p, normal
             std::vector<float> out;

@@ -11,6 +11,10 @@ The reference has no tests or golden vectors of its own, s
   <scene>_shadow    GenLight::Shadow (GenLight.cpp:10) for rays from primary hit points towards the light
   <scene>_render    per-sample radiance of MtlBlinn::Shade (MtlBlinn.cpp:89) over a pixel region, rand()
                     interposed by the sequential stream of include/bhrt_rng.h, plus the gamma/Color24 bytes
+  c5_caustics_photon  caustic photon map: emission, balance, gathers, radiance with the caustic term
+  global_photon       the global photon map (BuildPhotonMap, Main.cpp:251-317) of several scenes
+
+`make_golden.py global_photon` regenerates only the last one.
 """
 import hashlib
 import os
@@ -55,6 +59,10 @@ def main():
     if not os.path.exists(HARNESS):
         sys.exit("oracle/_ref/ref_harness missing: run `make -C oracle ref` in the development container")
     tmp = tempfile.mkdtemp(prefix="bhrt_golden_")
+    if sys.argv[1:] == ["global_photon"]:
+        global_photon_case(tmp)
+        subprocess.run(["rm", "-rf", tmp])
+        return
     for name, (xml, region, spp, gi) in CASES.items():
         pre = os.path.join(tmp, name)
         run(xml, pre, "dump", "primary")
@@ -111,6 +119,7 @@ def main():
         np.savez_compressed(path, **out)
         print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {int((pi[..., 0] >= 0).sum())}/{W * H} primary hits")
     photon_case(tmp)
+    global_photon_case(tmp)
     subprocess.run(["rm", "-rf", tmp])
 
 
@@ -143,6 +152,29 @@ def photon_case(tmp):
     np.savez_compressed(path, **out)
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {out['stored']} photons from {out['emitted']} emissions, "
           f"{int((out['gather_out'][:, :3].sum(1) > 0).sum())}/{len(q)} queries lit")
+
+
+GLOBAL_CASES = {"c5_caustics": 3000, "c2_glass_small": 2000, "c4_textured": 1500}
+
+
+def global_photon_case(tmp):
+    """Global photon map (BuildPhotonMap Main.cpp:251-295, TracePhotonRay Main.cpp:296-317, RandomPhotonBounce
+    MtlBlinn.cpp:140-202): the reference's emission loop with the photon budget as a parameter, then its own
+    ScalePhotonPowers + PrepareForIrradianceEstimation; one sequential rand() stream for the whole loop."""
+    out = {}
+    for name, n in GLOBAL_CASES.items():
+        pre = os.path.join(tmp, "g_" + name)
+        subprocess.run([HARNESS_PM, os.path.join(SCENES, name + ".xml"), pre, "--photons", str(n), "gphotons"], cwd=SCENES, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        meta = np.fromfile(pre + ".gphotons_meta", np.uint64)
+        out[name + "_n"] = n
+        out[name + "_meta"] = meta  # stored, emissions, rand() draws, halfStoredPhotons
+        out[name + "_emitted"] = np.fromfile(pre + ".gphotons_emitted", np.uint8).reshape(-1, 24)
+        out[name + "_balanced"] = np.fromfile(pre + ".gphotons_balanced", np.uint8).reshape(-1, 24)
+        print(f"global_photon/{name}: {int(meta[0])} photons from {int(meta[1])} emissions, {int(meta[2])} draws")
+    path = os.path.join(HERE, "global_photon.npz")
+    np.savez_compressed(path, **out)
+    print(f"global_photon: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 if __name__ == "__main__":

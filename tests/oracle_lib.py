@@ -104,6 +104,16 @@ def photon_build(blob: bytes, max_photons, seed=0, rng=RNG_KEYED, math=MATH_DEVI
     return out[:ns.value].copy(), unb, ne.value
 
 
+def photon_build_global(blob: bytes, max_photons, seed=0, rng=RNG_KEYED, math=MATH_DEVICE):
+    """BuildPhotonMap (Main.cpp:251-317): the global photon map.  Returns (balanced, emission order, emissions)."""
+    o = OracleOpts(1, 0, 0, seed, rng, math, 1, 0, 0, 0, 0, 1, 0)
+    out = np.zeros((max_photons, 24), np.uint8)
+    em = np.zeros((max_photons, 24), np.uint8)
+    ns, ne = C.c_uint32(0), C.c_uint64(0)
+    _check(lib().oracle_photon_build_global(C.c_char_p(blob), C.byref(o), int(max_photons), _p(out), _p(em), C.byref(ns), C.byref(ne)))
+    return out[: ns.value].copy(), em[: ns.value].copy(), int(ne.value)
+
+
 def photon_attach(balanced):
     a = np.ascontiguousarray(balanced, np.uint8)
     _check(lib().oracle_photon_attach(_p(a), a.shape[0]))

@@ -42,6 +42,24 @@ def test_oracle_photon_map_vs_reference_golden(load_scene, golden, O):
     assert same_bits(r["samples"], g["render_samples"])                    # Shade() with the caustic term (MtlBlinn.cpp:329-342)
 
 
+def test_oracle_global_photon_map_vs_reference_golden(load_scene, golden, O):
+    """BuildPhotonMap / TracePhotonRay / RandomPhotonBounce (Main.cpp:251-317, MtlBlinn.cpp:140-202) of the reference
+    (tests/golden/global_photon.npz) on a glass-over-plane scene, a box of diffuse and glossy objects far from the light
+    (~100 emissions per stored photon) and a textured scene: emission count, emitted bytes, balanced bytes."""
+    g = golden("global_photon")
+    for name in ("c5_caustics", "c2_glass_small", "c4_textured"):
+        sc = load_scene(name)
+        n = int(g[name + "_n"])
+        meta = g[name + "_meta"]
+        bal, emitted, n_emit = O.photon_build_global(sc.flat_bytes(), n, rng=O.RNG_SEQUENTIAL, math=O.MATH_LIBM)
+        assert len(bal) == int(meta[0]) == n and n_emit == int(meta[1]), name
+        check_photon_bytes(emitted, g[name + "_emitted"])
+        check_photon_bytes(bal, g[name + "_balanced"], int(np.int64(meta[3])))
+    # not the caustic map: photons are stored at the first diffuse hit too
+    cb, _, ce = O.photon_build(load_scene("c5_caustics").flat_bytes(), 3000, rng=O.RNG_SEQUENTIAL, math=O.MATH_LIBM)
+    assert ce > 10 * int(g["c5_caustics_meta"][1])
+
+
 def test_photon_record_layout_and_direction_quirk(load_scene, O):
     sc = load_scene("c5_caustics")
     bal, emitted, _ = O.photon_build(sc.flat_bytes(), 500)
@@ -142,6 +160,28 @@ def test_gpu_photon_map_vs_oracle(B, load_scene, O):
     assert same_bits(gi3, oi3) and same_bits(gd3, od3)
     with pytest.raises(B.BhrtError):
         sc2.photon_import(path + ".missing")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n", [("c5_caustics", 50000), ("c2_glass_small", 3000), ("c4_textured", 3000), ("c3_mesh_small", 3000)])
+def test_gpu_global_photon_map_vs_oracle(name, n, B, load_scene, O, tmp_path):
+    """bhrt_photon_build_global: every byte of the balanced global map equals the oracle's (keyed streams, device math);
+    the .dat it writes holds the same records; the caustic map installed for gathers is left alone."""
+    if B.device_count() < 1:
+        pytest.fail("no HIP device")
+    sc = load_scene(name)
+    opts = B.default_opts(seed=5)
+    dat = str(tmp_path / "photonmap.dat")
+    got = sc.photon_build_global(opts, n, dat_path=dat)
+    bal, _, n_emit = O.photon_build_global(sc.flat_bytes(), n, seed=5)
+    assert len(got) == len(bal) == n and n_emit > 0
+    assert np.array_equal(got, bal)
+    assert np.array_equal(np.fromfile(dat, np.uint8).reshape(-1, 24), bal)
+    if name == "c5_caustics":
+        k = sc.photon_build(opts, 2000)
+        before = sc.photon_get()
+        sc.photon_build_global(opts, 500)
+        assert k == 2000 and np.array_equal(sc.photon_get(), before)
 
 
 @pytest.mark.gpu

@@ -198,3 +198,13 @@ def test_random_scenes_photon_map_reference_vs_oracle(B, O, tmp_path):
         assert np.array_equal(bal[:, m], ref_bal[:, m]) and np.array_equal(bal[:, 19] & 8, ref_bal[:, 19] & 8), seed
         internal = np.arange(1, len(ref_bal) + 1) < int(meta[3])
         assert np.array_equal(bal[internal, 19] & 3, ref_bal[internal, 19] & 3), seed
+        # the global map (BuildPhotonMap) of the same scene
+        subprocess.run([harness_pm, xml, pre, "--seed", str(seed), "--photons", "1200", "gphotons"], cwd=str(tmp_path), check=True, timeout=120,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        bal, emitted, n_emit = O.photon_build_global(sc.flat_bytes(), 1200, seed=seed, rng=O.RNG_SEQUENTIAL, math=O.MATH_LIBM)
+        meta = np.fromfile(pre + ".gphotons_meta", np.uint64)
+        assert n_emit == int(meta[1]), seed
+        ref_em = np.fromfile(pre + ".gphotons_emitted", np.uint8).reshape(-1, 24)
+        ref_bal = np.fromfile(pre + ".gphotons_balanced", np.uint8).reshape(-1, 24)
+        assert np.array_equal(emitted[:, m], ref_em[:, m]) and np.array_equal(emitted[:, 19] & 8, ref_em[:, 19] & 8), seed
+        assert np.array_equal(bal[:, m], ref_bal[:, m]) and np.array_equal(bal[:, 19] & 8, ref_bal[:, 19] & 8), seed
