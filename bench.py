@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--samples-per-pass", type=int, default=0, help="camera samples in flight per wavefront pass (0 = library default)")
+    ap.add_argument("--timers", type=int, default=None, help="bhrt_opts.timers: 0 = HIP events around k_shade only (default for c2, whose dominant kernel it is), 1 = around every kernel group (default otherwise; costs ~0.2 ms of event gaps per frame), -1 = none")
     ap.add_argument("--photons", type=int, default=1000000, help="photon budget of workload c5 (MAX_CausticPhotonCount, Main.cpp:53)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: all ranks share cuda:0 and the gather goes through gloo on host copies, "
@@ -149,6 +150,7 @@ def main():
     tile = 32
     opts = B.default_opts(spp=spp, gi_bounces=gi, internal_bounces=16, seed=0, rank=rank, world_size=N, tile_size=tile)
     opts.samples_per_pass = args.samples_per_pass
+    opts.timers = args.timers if args.timers is not None else (0 if args.workload == "c2" else 1)
     photon_build_s = None
     if args.workload == "c5":
         t0 = time.perf_counter()
@@ -248,7 +250,7 @@ def main():
             "photon_heap_pass_s_per_frame": (agg.get("reserved1", 0.0) / args.steps) if photon_build_s else None,
             "photon_heap_queries_per_frame": (agg.get("reserved2", 0.0) / args.steps) if photon_build_s else None,
             "photon_wave_queries_per_frame": (agg.get("reserved3", 0.0) / args.steps) if photon_build_s else None,
-            "kernel_seconds": k_times,
+            "kernel_seconds": k_times, "timers": {0: "k_shade only", 1: "every kernel group", -1: "none"}.get(opts.timers),
             "kernels": per_kernel,
             "wave_steps_per_frame": agg["wave_iterations"] / args.steps,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,

@@ -435,6 +435,18 @@ __global__ void __launch_bounds__(128) k_order_prefix(Counters *cnt, RayOrder or
     }
 }
 
+// The step's queue lengths for the host, written straight into pinned host memory (no copy engine packet, no event:
+// each of those costs the stream ~6 us of idle GPU per wave step).  The host spins on `seq` (WaitPublished).
+struct HostCounters { uint32_t n_next, n_shadow, n_frames, overflow; uint32_t pad[12]; uint32_t seq; };
+__global__ void __launch_bounds__(64) k_publish(const Counters *cnt, HostCounters *pub, uint32_t seq)
+{
+    if (threadIdx.x != 0) return;
+    volatile HostCounters *p = pub;
+    p->n_next = cnt->n_next.v; p->n_shadow = cnt->n_shadow.v; p->n_frames = cnt->n_frames.v; p->overflow = cnt->overflow.v;
+    __threadfence_system();
+    __hip_atomic_store(&pub->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------------------------------------------------
 // One Shade() entry (MtlBlinn.cpp:89-138): fills frame f, produces up to two closest rays and one shadow ray.
 struct ShadeOut {
@@ -1172,14 +1184,16 @@ struct DeviceState {
     uint32_t *d_seg = nullptr;                 // seg_start[97] + seg_count[96] + mesh_start[33] + mesh_count[33] + frame_base[96]
     uint32_t *d_park = nullptr;                // park_key[cap_rays] + park_sorted[cap_rays] + buckets + tile sums (RayOrder)
     Counters *d_cnt = nullptr;
-    Counters *h_cnt = nullptr; // pinned
+    HostCounters *h_pub = nullptr; // pinned, device-visible: written by k_publish
+    HostCounters *d_pub = nullptr; // the device's address of h_pub
+    uint32_t pub_seq = 0;
+    int timers = 0;                // bhrt_opts.timers of the running call
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     struct PendingTimer { int e0, e1; double *acc; };
     std::vector<hipEvent_t> ev_pool;
     std::vector<PendingTimer> ev_pending;
     std::vector<int> ev_free;                  // pool indices not in use
-    hipEvent_t ev_counts = nullptr;            // "the step's counters have reached the host"
     // caustic photon map (balanced, heap order, slot 0 unused) + gather scratch
     DPhoton *d_photons = nullptr;
     uint32_t n_photons = 0;
@@ -1212,10 +1226,9 @@ void DestroyDeviceState(DeviceState *d)
     fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_park); fr(d->d_seg); fr(d->d_cnt); fr(d->d_aux);
     fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_cells); fr(d->d_tile_sums);
     if (d->h_n_heavy) (void)hipHostFree(d->h_n_heavy);
-    if (d->h_cnt) (void)hipHostFree(d->h_cnt);
+    if (d->h_pub) (void)hipHostFree(d->h_pub);
     for (int k = 0; k < 2; k++) if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
     for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
-    if (d->ev_counts) (void)hipEventDestroy(d->ev_counts);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -1308,10 +1321,13 @@ static uint64_t CountValidPixels(const PassInfo &P, uint32_t n)
 
 // Kernel timing with HIP events on the library's stream, without a host round trip per kernel: start/stop events
 // come from a pool and are only read back (FlushTimers) after a stream synchronisation the pipeline needs anyway.
+// bhrt_opts.timers: 0 = the shading kernel only (the dominant one; bench.py's roofline), 1 = every kernel group, -1 = none.
+// An event between two kernels costs ~6 us of idle GPU, which is why the default does not time everything.
 struct Timer {
     DeviceState *D;
     double *acc;
     int e0;
+    bool on;
     static hipEvent_t Get(DeviceState *d, int &idx)
     {
         if (d->ev_free.empty()) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); d->ev_pool.push_back(e); d->ev_free.push_back((int)d->ev_pool.size() - 1); }
@@ -1319,14 +1335,32 @@ struct Timer {
         d->ev_free.pop_back();
         return d->ev_pool[idx];
     }
-    Timer(DeviceState *d, double *a) : D(d), acc(a) { (void)hipEventRecord(Get(D, e0), D->stream); }
+    Timer(DeviceState *d, double *a, int level = 1) : D(d), acc(a), e0(-1), on(d->timers >= level) { if (on) (void)hipEventRecord(Get(D, e0), D->stream); }
     void Stop()
     {
+        if (!on) return;
         int e1;
         (void)hipEventRecord(Get(D, e1), D->stream);
         D->ev_pending.push_back({e0, e1, acc});
     }
 };
+// Host side of k_publish: spins until the step's counters have arrived.  Leaves the loop when the stream reports an error
+// or has drained without the flag appearing.
+static int WaitPublished(DeviceState *D, uint32_t seq)
+{
+    auto arrived = [&]() { return __atomic_load_n(&D->h_pub->seq, __ATOMIC_ACQUIRE) == seq; };
+    for (uint64_t spin = 1; !arrived(); spin++) {
+        __builtin_ia32_pause();
+        if ((spin & 0xffff) == 0) {
+            const hipError_t e = hipStreamQuery(D->stream);
+            if (e == hipErrorNotReady) continue;
+            if (e != hipSuccess) { SetError(std::string("stream error while waiting for the step counters: ") + hipGetErrorString(e)); return BHRT_ERR_HIP; }
+            if (!arrived()) { SetError("stream drained without publishing the step counters"); return BHRT_ERR_HIP; }
+        }
+    }
+    return BHRT_OK;
+}
+
 // Reads back the timers whose kernels have finished; the others (kernels launched ahead of the host, e.g. the shadow
 // trace of the current step) stay pending until a later call.  final = true: after a full stream synchronisation.
 static void FlushTimers(DeviceState *D, bool final = false)
@@ -1409,7 +1443,7 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
     const uint32_t heap_lanes = 1u << 20; // as many heaps in flight as possible: the pass is a chain of dependent accesses per query (65 k lanes: 1.8x slower)
     int rc = EnsurePhotonScratch(D, std::min<uint32_t>(heap_lanes, (n_heavy + 4095u) & ~4095u));
     if (rc) return rc;
-    Timer t(D, st ? &st->reserved[1] : nullptr);
+    Timer t(D, st ? &st->reserved[1] : nullptr, 0);
     const uint32_t chunk = std::min<uint32_t>(D->scr_lanes, heap_lanes);
     for (uint32_t h0 = 0; h0 < n_heavy; h0 += chunk) {
         const uint32_t m = std::min<uint32_t>(chunk, n_heavy - h0);
@@ -1457,6 +1491,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
     pass_samples = (uint32_t)std::min<uint64_t>(pass_samples, std::max<uint64_t>(owned_pixels * (uint64_t)o.spp, 1)); // never more than this render needs
     if (pass_samples < (uint32_t)o.spp) pass_samples = (uint32_t)o.spp;
     const uint32_t frames_per_sample = 6; // Shade() frames per camera sample; an overflow halves the pass and retries
+    D->timers = o.timers;
     RenderParams R;
     R.internal_bounces = o.internal_bounces; R.gi_bounces = o.gi_bounces; R.photon = o.photon_map;
     auto wall0 = std::chrono::steady_clock::now();
@@ -1521,15 +1556,15 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             st->launches_trace_closest++;
             hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(128), 0, D->stream, D->d_cnt, RO);
             {
-                Timer t(D, &st->seconds_shade);
+                Timer t(D, &st->seconds_shade, 0);
                 const dim3 sg((n_cur + kShadeBlock - 1) / kShadeBlock + 3 * BHRT_ORDER_SHARDS), sb(kShadeBlock);
                 const bool tex = H->n_texmaps > 0;
                 auto shade = first_step ? (tex ? k_shade<true, true> : k_shade<true, false>) : (tex ? k_shade<false, true> : k_shade<false, false>);
                 hipLaunchKernelGGL(shade, sg, sb, 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt, RO);
                 t.Stop();
             }
-            HIP_CHECK(hipMemcpyAsync(D->h_cnt, D->d_cnt, BHRT_COUNTERS_HOST_BYTES, hipMemcpyDeviceToHost, D->stream)); // n_next, n_shadow, n_frames, overflow
-            HIP_CHECK(hipEventRecord(D->ev_counts, D->stream));
+            const uint32_t seq = ++D->pub_seq;
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, D->stream, D->d_cnt, D->d_pub, seq); // n_next, n_shadow, n_frames, overflow
             { // the shadow trace of this step goes out before the host has the counters: its grid covers the upper bound
               // (<= 1 shadow ray per shaded ray, <= the queue's capacity) and the kernels read the length on the device
                 Timer t(D, &st->seconds_trace_shadow);
@@ -1542,26 +1577,28 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 } else hipLaunchKernelGGL(k_trace_shadow, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis);
                 t.Stop();
             }
-            HIP_CHECK(hipEventSynchronize(D->ev_counts));
+            rc = WaitPublished(D, seq);
+            if (rc) return rc;
+            const HostCounters hc = *D->h_pub;
             FlushTimers(D);
-            if (D->h_cnt->overflow.v) { overflow = true; break; }
+            if (hc.overflow) { overflow = true; break; }
             if (first_step) { // camera step: dead rays of edge tiles are not rays
                 const uint64_t valid_px = CountValidPixels(P, npx);
                 pass_closest = valid_px * (uint64_t)o.spp;
                 st->camera_samples += pass_closest;
                 first_step = false;
             } else pass_closest += n_cur;
-            const uint32_t n_sh = D->h_cnt->n_shadow.v;
+            const uint32_t n_sh = hc.n_shadow;
             if (n_sh) { st->shadow_rays += n_sh; st->launches_trace_shadow++; }
-            if (o.photon_map && D->h_cnt->n_frames.v > frame_marks.back()) { // caustic term of the frames opened in this step
-                Timer t(D, &st->reserved[0]);
+            if (o.photon_map && hc.n_frames > frame_marks.back()) { // caustic term of the frames opened in this step
+                Timer t(D, &st->reserved[0], 0);
                 const GatherToFrames sink = {F, D->S.materials};
-                rc = RunGather(D, sink, frame_marks.back(), D->h_cnt->n_frames.v - frame_marks.back(), 0.5f /* MAX_Area, MtlBlinn.cpp:29 */, st);
+                rc = RunGather(D, sink, frame_marks.back(), hc.n_frames - frame_marks.back(), 0.5f /* MAX_Area, MtlBlinn.cpp:29 */, st);
                 if (rc) return rc;
                 t.Stop();
             }
-            frame_marks.push_back(D->h_cnt->n_frames.v);
-            n_cur = D->h_cnt->n_next.v;
+            frame_marks.push_back(hc.n_frames);
+            n_cur = hc.n_next;
             cur ^= 1;
             st->wave_iterations++;
         }
@@ -1572,7 +1609,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             pass_limit = std::max<uint32_t>((uint32_t)o.spp, pass_limit / 2);
             continue;
         }
-        st->shade_calls += D->h_cnt->n_frames.v;
+        st->shade_calls += D->h_pub->n_frames;
         st->closest_rays += pass_closest;
         {
             Timer t(D, &st->seconds_other);
@@ -1642,8 +1679,9 @@ int bhrt_scene_upload(bhrt_scene *scene, int device)
     HIP_CHECK(hipMemcpy(D->d_chain, chain.data(), chain.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&D->d_cnt, sizeof(Counters)));
     HIP_CHECK(hipMalloc(&D->d_seg, (11 * BHRT_ORDER_SHARDS + 3) * sizeof(uint32_t)));
-    HIP_CHECK(hipHostMalloc(&D->h_cnt, sizeof(Counters)));
-    HIP_CHECK(hipEventCreateWithFlags(&D->ev_counts, hipEventDisableTiming));
+    HIP_CHECK(hipHostMalloc(&D->h_pub, sizeof(HostCounters), hipHostMallocMapped));
+    memset(D->h_pub, 0, sizeof(HostCounters));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&D->d_pub, D->h_pub, 0));
     DevScene &S = D->S;
     S.blob = D->d_blob;
     S.nodes = (const bhrt_node *)(D->d_blob + H->off_nodes);
@@ -2021,6 +2059,7 @@ int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *nrm,
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     DeviceState *D = scene->dev;
+    D->timers = 0;
     if (!D->d_photons) { SetError("photon map: call bhrt_photon_build first"); return BHRT_ERR_ARG; }
     if (!p || !nrm || !irrad || !dir) { SetError("null buffer"); return BHRT_ERR_ARG; }
     if (cnt == 0) return BHRT_OK;

@@ -66,7 +66,9 @@ typedef struct bhrt_opts {
     int32_t rank, world_size;
     int32_t tile_size;        /* square tile edge in pixels, default 32 */
     int32_t samples_per_pass; /* 0 = choose; upper bound on camera samples in flight per wavefront pass */
-    int32_t reserved[5];
+    int32_t timers;           /* HIP-event kernel timers of bhrt_stats: 0 = seconds_shade only (default; an event between two kernels
+                               * idles the GPU ~6 us), 1 = all kernel groups, -1 = none */
+    int32_t reserved[4];
 } bhrt_opts;
 
 typedef struct bhrt_stats {
