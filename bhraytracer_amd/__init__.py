@@ -66,6 +66,7 @@ EXPORTS = [
     "bhrt_render", "bhrt_render_dev", "bhrt_render_samples", "bhrt_photon_build", "bhrt_photon_gather_host",
     "bhrt_photon_get", "bhrt_photon_export", "bhrt_photon_import", "bhrt_photon_build_global", "bhrt_save_png", "bhrt_math_eval_dev",
     "bhrt_tiles_block_bytes", "bhrt_tiles_pack_dev", "bhrt_tiles_unpack_dev",
+    "bhrt_first_hit", "bhrt_first_hit_dev", "bhrt_zbuffer_image_dev", "bhrt_color_image_dev",
 ]
 
 
@@ -206,6 +207,27 @@ class Scene:
         _check(lib().bhrt_render_dev(self._h, C.byref(opts), C.c_void_p(d_rgb8_ptr or None),
                                      C.c_void_p(d_radiance_ptr or None), C.byref(st), None))
         return st
+
+    # ---- images beside the colour image (RenderImage z-buffer, DenoiseImage inputs) ------------
+    def first_hit(self):
+        """First hit of every pixel's un-jittered camera ray: z (H, W), normal (H, W, 3), albedo (H, W, 3), host arrays."""
+        H, W = self.height, self.width
+        z, nrm, alb = np.zeros((H, W), np.float32), np.zeros((H, W, 3), np.float32), np.zeros((H, W, 3), np.float32)
+        _check(lib().bhrt_first_hit(self._h, _ptr(z), _ptr(nrm), _ptr(alb)))
+        return z, nrm, alb
+
+    def first_hit_dev(self, d_z: int = 0, d_normal: int = 0, d_albedo: int = 0, stream: int = 0):
+        _check(lib().bhrt_first_hit_dev(self._h, C.c_void_p(d_z or None), C.c_void_p(d_normal or None), C.c_void_p(d_albedo or None),
+                                        C.c_void_p(stream or None)))
+
+    def zbuffer_image_dev(self, d_z: int, n: int, d_img: int, stream: int = 0):
+        """RenderImage::ComputeZBufferImage (scene.h:578-600) on device buffers."""
+        _check(lib().bhrt_zbuffer_image_dev(self._h, C.c_void_p(d_z), C.c_size_t(n), C.c_void_p(d_img), C.c_void_p(stream or None)))
+
+    def color_image_dev(self, d_radiance: int, n_pixels: int, gamma: int, d_color: int, stream: int = 0):
+        """colorArray of BeginRender (Main.cpp:219-229): the gamma-corrected float image DenoiseImage is given."""
+        _check(lib().bhrt_color_image_dev(self._h, C.c_void_p(d_radiance), C.c_size_t(n_pixels), int(gamma), C.c_void_p(d_color),
+                                          C.c_void_p(stream or None)))
 
     # ---- caustic photon map ------------------------------------------------------------------
     def photon_build(self, opts: Opts, max_photons: int) -> int:

@@ -868,6 +868,80 @@ __global__ void __launch_bounds__(kBlock) k_resolve(PassInfo P, const float *sam
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Images beside the colour image: RenderImage's z-buffer (scene.h:532, the store commented out at
+// Main.cpp:231) and the albedo / normal inputs DenoiseImage leaves unset (Main.cpp:70-71), all from the first hit of the
+// un-jittered camera ray of every pixel (the pixel corner).  One lane per pixel, row-major.
+__global__ void __launch_bounds__(kBlock) k_first_hit(DevScene S, int W, int H, float *z, float *normal, float *albedo)
+{
+    __shared__ bhrt_bvh_node nodelet[BHRT_LDS_NODES];
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = q < (uint32_t)(W * H);
+    const int j = (int)(q / (uint32_t)W), i = (int)(q - (uint32_t)j * (uint32_t)W);
+    const V3 topLeft = ld3(S.cam.top_left), ddx = ld3(S.cam.dd_x), ddy = ld3(S.cam.dd_y), pos = ld3(S.cam.pos);
+    const V3 o = pos, d = ((topLeft + (float)i * ddx) - (float)j * ddy) - pos; // Main.cpp:145,153
+    Hit hit;
+    trace_closest(S, o, d, BHRT_HIT_FRONT, hit, active, nodelet); // uniform call: the block stages nodelets together
+    if (!active) return;
+    V3 N = v3(0, 0, 0), kd = v3(0, 0, 0);
+    if (hit.node >= 0 && (normal || albedo)) {
+        const int mi = S.nodes[hit.node].material;
+        const bool blinn = mi >= 0 && S.materials[mi].kind == BHRT_MTL_BLINN;
+        Attr a;
+        hit_attrs(S, o, d, hit.t, hit.node, hit.prim, albedo && blinn && S.materials[mi].diffuse.map >= 0, a);
+        N = a.N;
+        if (blinn) kd = tc_sample_d(S, S.materials[mi].diffuse, a.uvw, a.du, a.dv); // diffuse.Sample(uvw, duvw), MtlBlinn.cpp:393
+        else if (mi >= 0 && S.materials[mi].kind == BHRT_MTL_WHITE) kd = v3(1, 1, 1);
+    }
+    if (z) z[q] = hit.node >= 0 ? hit.t : BHRT_BIGFLOAT;
+    if (normal) st3(normal, q, N);
+    if (albedo) st3(albedo, q, kd);
+}
+
+// RenderImage::ComputeZBufferImage (scene.h:578-600): min / max over the hits, then (zmax - z) / (zmax - zmin) * 255 truncated.
+// Min and max are exact in any order; one workgroup strides over the image.
+__global__ void __launch_bounds__(1024) k_z_range(const float *z, uint32_t n, float *range)
+{
+    __shared__ float s_min[1024], s_max[1024];
+    float zmin = BHRT_BIGFLOAT, zmax = 0;
+    for (uint32_t k = threadIdx.x; k < n; k += 1024) {
+        const float v = z[k];
+        if (v == BHRT_BIGFLOAT) continue;
+        if (zmin > v) zmin = v;
+        if (zmax < v) zmax = v;
+    }
+    s_min[threadIdx.x] = zmin; s_max[threadIdx.x] = zmax;
+    __syncthreads();
+    for (uint32_t w = 512; w > 0; w >>= 1) {
+        if (threadIdx.x < w) {
+            if (s_min[threadIdx.x] > s_min[threadIdx.x + w]) s_min[threadIdx.x] = s_min[threadIdx.x + w];
+            if (s_max[threadIdx.x] < s_max[threadIdx.x + w]) s_max[threadIdx.x] = s_max[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { range[0] = s_min[0]; range[1] = s_max[0]; }
+}
+__global__ void __launch_bounds__(kBlock) k_z_image(const float *z, uint32_t n, const float *range, uint8_t *img)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float zmin = range[0], zmax = range[1], v = z[k];
+    if (v == BHRT_BIGFLOAT) { img[k] = 0; return; }
+    const float f = (zmax - v) / (zmax - zmin);
+    int c = f != f ? (int)0x80000000 : (f >= 2147483648.f ? (int)0x80000000 : (f * 255 <= -2147483648.f ? (int)0x80000000 : int(f * 255))); // x86 cvttss2si out-of-range / NaN value
+    if (c < 0) c = 0;
+    if (c > 255) c = 255;
+    img[k] = (uint8_t)c;
+}
+// colorArray of BeginRender (Main.cpp:202,219-229): the gamma-corrected pixel colour as floats = DenoiseImage's "color" input
+__global__ void __launch_bounds__(kBlock) k_color_image(const float *radiance, uint32_t n3, int gamma, float *color)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n3) return;
+    const float c = radiance[k];
+    color[k] = gamma ? dm::powf_(c, 1 / 2.2f) : c;
+}
+
 // test hook: the deterministic math of bhrt_detmath.h evaluated on the device (tests compare its bits with the host's)
 __global__ void k_math_eval(int fn, const float *a, const float *b, uint32_t n, float *out)
 {
@@ -1860,7 +1934,72 @@ int bhrt_render_samples(bhrt_scene *scene, const bhrt_opts *opts, int x0, int y0
     return rc;
 }
 
-// ---- caustic photon map --------------------------------------------------------------------------
+// ---- images beside the colour image ---------------------------------------------------------------
+int bhrt_first_hit_dev(bhrt_scene *scene, float *d_z, float *d_normal, float *d_albedo, void *stream)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    DeviceState *D = scene->dev;
+    const bhrt_flat_header *H = scene->flat.hdr();
+    const int W = H->camera.width, Hh = H->camera.height;
+    if (!d_z && !d_normal && !d_albedo) return BHRT_OK;
+    hipStream_t st = stream ? (hipStream_t)stream : D->stream;
+    hipLaunchKernelGGL(k_first_hit, dim3(((uint32_t)(W * Hh) + kBlock - 1) / kBlock), dim3(kBlock), 0, st, D->S, W, Hh, d_z, d_normal, d_albedo);
+    HIP_CHECK(hipGetLastError());
+    if (!stream) HIP_CHECK(hipStreamSynchronize(st));
+    return BHRT_OK;
+}
+
+int bhrt_first_hit(bhrt_scene *scene, float *z, float *normal, float *albedo)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    DeviceState *D = scene->dev;
+    const bhrt_flat_header *H = scene->flat.hdr();
+    const size_t n = (size_t)H->camera.width * H->camera.height;
+    float *d = nullptr;
+    HIP_CHECK(hipMalloc(&d, n * 7 * sizeof(float)));
+    rc = bhrt_first_hit_dev(scene, z ? d : nullptr, normal ? d + n : nullptr, albedo ? d + 4 * n : nullptr, nullptr);
+    hipError_t e = hipSuccess;
+    if (!rc && z) e = hipMemcpy(z, d, n * sizeof(float), hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess && normal) e = hipMemcpy(normal, d + n, 3 * n * sizeof(float), hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess && albedo) e = hipMemcpy(albedo, d + 4 * n, 3 * n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    (void)D;
+    if (rc) return rc;
+    HIP_CHECK(e);
+    return BHRT_OK;
+}
+
+int bhrt_zbuffer_image_dev(bhrt_scene *scene, const float *d_z, size_t n, uint8_t *d_img, void *stream)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    if (!d_z || !d_img || n == 0 || n > 0xffffffffull) { SetError("bad z-buffer arguments"); return BHRT_ERR_ARG; }
+    DeviceState *D = scene->dev;
+    rc = EnsureApiScratch(D, 16);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : D->stream;
+    hipLaunchKernelGGL(k_z_range, dim3(1), dim3(1024), 0, st, d_z, (uint32_t)n, D->d_api_f);
+    hipLaunchKernelGGL(k_z_image, dim3(((uint32_t)n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, d_z, (uint32_t)n, D->d_api_f, d_img);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(st)); // the range scratch is shared with the other API calls
+    return BHRT_OK;
+}
+
+int bhrt_color_image_dev(bhrt_scene *scene, const float *d_radiance, size_t n_pixels, int gamma, float *d_color, void *stream)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    if (!d_radiance || !d_color || n_pixels * 3 > 0xffffffffull) { SetError("bad colour image arguments"); return BHRT_ERR_ARG; }
+    DeviceState *D = scene->dev;
+    hipStream_t st = stream ? (hipStream_t)stream : D->stream;
+    if (n_pixels) hipLaunchKernelGGL(k_color_image, dim3(((uint32_t)(n_pixels * 3) + kBlock - 1) / kBlock), dim3(kBlock), 0, st, d_radiance, (uint32_t)(n_pixels * 3), gamma, d_color);
+    HIP_CHECK(hipGetLastError());
+    if (!stream) HIP_CHECK(hipStreamSynchronize(st));
+    return BHRT_OK;
+}
+
 static bool TileArgsOk(int W, int H, int tile, int rank, int world)
 {
     if (W <= 0 || H <= 0 || tile <= 0 || world <= 0 || rank < 0 || rank >= world) { SetError("bad tile partition"); return false; }

@@ -151,6 +151,21 @@ int bhrt_tiles_pack_dev(const uint8_t *d_rgb8, const float *d_radiance, int widt
 int bhrt_tiles_unpack_dev(const void *d_blocks /* world blocks, rank-major */, int width, int height, int tile, int world, uint8_t *d_rgb8, float *d_radiance,
                           void *stream);
 
+/* ---- images beside the colour image ------------------------------------------
+ * First hit of the un-jittered camera ray of every pixel (the pixel corner: `1 / 2 == 0`, Main.cpp:145), row-major:
+ *   z       W*H floats      HitInfo::z, BIGFLOAT where nothing is hit = RenderImage::GetZBuffer() (scene.h:532; its store is
+ *                           commented out at Main.cpp:231)
+ *   normal  W*H*3 floats    HitInfo::N in world space (zero on a miss)   \ the optional "normal" / "albedo" images of
+ *   albedo  W*H*3 floats    diffuse.Sample(uvw, duvw) of the hit material / DenoiseImage (Main.cpp:70-71, commented out there)
+ * Any pointer may be NULL. */
+int bhrt_first_hit_dev(bhrt_scene *scene, float *d_z, float *d_normal, float *d_albedo, void *stream);
+int bhrt_first_hit(bhrt_scene *scene, float *z, float *normal, float *albedo);
+/* RenderImage::ComputeZBufferImage (scene.h:578-600): 8-bit depth image, 0 where nothing is hit.  Device pointers. */
+int bhrt_zbuffer_image_dev(bhrt_scene *scene, const float *d_z, size_t n, uint8_t *d_img, void *stream);
+/* colorArray of BeginRender (Main.cpp:202,219-229): pow(colour, 1/2.2f) as floats — the "color" image DenoiseImage is given
+ * (Main.cpp:60-69).  d_radiance = the radiance image of bhrt_render_dev. */
+int bhrt_color_image_dev(bhrt_scene *scene, const float *d_radiance, size_t n_pixels, int gamma, float *d_color, void *stream);
+
 /* ---- test hook: csrc/bhrt_detmath.h evaluated on the device, to prove host and device produce the same bits.
  * fn: 0 sin 1 cos 2 tan 3 acos 4 asin 5 atan2(a,b) 6 pow(a,b) 7 rand_to_unit(bits of a) 8 a/b 9 sqrt(a); host pointers */
 int bhrt_math_eval_dev(int fn, const float *a, const float *b, size_t n, float *out);

@@ -1088,6 +1088,40 @@ template <class M> void PushAttrs(float *a, const HitInfo &h)
     a[10] = h.duvw[0].x; a[11] = h.duvw[0].y; a[12] = h.duvw[0].z; a[13] = h.duvw[1].x; a[14] = h.duvw[1].y; a[15] = h.duvw[1].z;
 }
 
+// Images beside the colour image: first hit of the un-jittered camera ray (Main.cpp:145,153), z = HitInfo::z (the store
+// commented out at Main.cpp:231), world-space normal and diffuse.Sample(uvw, duvw) (MtlBlinn.cpp:393) of the hit material.
+template <class M> int FirstHitT(const Scene &S, float *z, float *normal, float *albedo)
+{
+    const bhrt_camera &cam = S.H->camera;
+    const Vec3 topLeft(cam.top_left[0], cam.top_left[1], cam.top_left[2]);
+    const Vec3 dd_x = S.dd_x, dd_y = S.dd_y;
+    const Vec3 camPos(cam.pos[0], cam.pos[1], cam.pos[2]);
+    Textures<M> X(S);
+    Tracer<M> T(S, nullptr);
+    for (int j = 0; j < cam.height; j++)
+        for (int i = 0; i < cam.width; i++) {
+            const size_t pix = (size_t)j * cam.width + i;
+            Ray ray;
+            ray.p = camPos;
+            ray.dir = (topLeft + (float)(i + 1 / 2) * dd_x - (float)(j + 1 / 2) * dd_y) - camPos;
+            bool bHit = false;
+            HitInfo h;
+            T.Closest(ray, h, bHit, BHRT_HIT_FRONT);
+            Vec3 N(0, 0, 0);
+            Color kd = Black();
+            if (bHit) {
+                N = h.N;
+                const int mi = S.nodes[h.node].material;
+                if (mi >= 0 && S.materials[mi].kind == BHRT_MTL_BLINN) kd = X.Sample(S.materials[mi].diffuse, h.uvw, h.duvw);
+                else if (mi >= 0 && S.materials[mi].kind == BHRT_MTL_WHITE) kd = Color(1, 1, 1);
+            }
+            if (z) z[pix] = bHit ? h.z : BHRT_BIGFLOAT;
+            if (normal) { normal[pix * 3] = N.x; normal[pix * 3 + 1] = N.y; normal[pix * 3 + 2] = N.z; }
+            if (albedo) { albedo[pix * 3] = kd.r; albedo[pix * 3 + 1] = kd.g; albedo[pix * 3 + 2] = kd.b; }
+        }
+    return 0;
+}
+
 } // namespace
 
 // The note in GetRandomCrossingVector: `Vec3f(Rnd01(), Rnd01(), Rnd01())` has unspecified argument evaluation
@@ -1139,6 +1173,44 @@ int oracle_render(const void *blob, const oracle_opts *opts, float *samples, flo
     if (!S.Init(blob)) return 1;
     if (opts->math_mode == ORACLE_MATH_DEVICE) return RenderT<MathDevice>(S, *opts, samples, radiance, rgb8, stats);
     return RenderT<MathLibm>(S, *opts, samples, radiance, rgb8, stats);
+}
+
+int oracle_first_hit(const void *blob, int math_mode, float *z, float *normal, float *albedo)
+{
+    Scene S;
+    if (!S.Init(blob)) return 1;
+    return math_mode == ORACLE_MATH_DEVICE ? FirstHitT<MathDevice>(S, z, normal, albedo) : FirstHitT<MathLibm>(S, z, normal, albedo);
+}
+
+// RenderImage::ComputeZBufferImage, scene.h:578-600
+int oracle_zbuffer_image(const float *zbuffer, size_t size, uint8_t *zbufferImg)
+{
+    float zmin = BHRT_BIGFLOAT, zmax = 0;
+    for (size_t i = 0; i < size; i++) {
+        if (zbuffer[i] == BHRT_BIGFLOAT) continue;
+        if (zmin > zbuffer[i]) zmin = zbuffer[i];
+        if (zmax < zbuffer[i]) zmax = zbuffer[i];
+    }
+    for (size_t i = 0; i < size; i++) {
+        if (zbuffer[i] == BHRT_BIGFLOAT) zbufferImg[i] = 0;
+        else {
+            float f = (zmax - zbuffer[i]) / (zmax - zmin);
+            int c = int(f * 255);
+            if (c < 0) c = 0;
+            if (c > 255) c = 255;
+            zbufferImg[i] = (uint8_t)c;
+        }
+    }
+    return 0;
+}
+
+// colorArray of BeginRender, Main.cpp:219-229: pow(outColor, 1/2.2f) per channel, kept as floats
+int oracle_color_image(const float *radiance, size_t n_floats, int gamma, int math_mode, float *color)
+{
+    const float inverseGama = 1 / 2.2f;
+    for (size_t i = 0; i < n_floats; i++)
+        color[i] = !gamma ? radiance[i] : (math_mode == ORACLE_MATH_DEVICE ? MathDevice::Pow(radiance[i], inverseGama) : MathLibm::Pow(radiance[i], inverseGama));
+    return 0;
 }
 
 int oracle_math_eval(int fn, int math_mode, const float *a, const float *b, size_t n, float *out)

@@ -67,6 +67,11 @@ int oracle_math_eval(int fn, int math_mode, const float *a, const float *b, size
 /* caustic photon map (Main.cpp:342-386, cyPhotonMap.h) — see bhrt_oracle.cpp */
 int oracle_photon_build(const void *blob, const oracle_opts *opts, uint32_t max_photons, void *photons_out /* 24 B each */,
                         uint32_t *n_stored, uint64_t *n_emitted);
+/* images beside the colour image: first hit of every pixel's un-jittered camera ray (z: Main.cpp:231 / scene.h:532; normal and
+ * albedo: the optional DenoiseImage inputs, Main.cpp:70-71), ComputeZBufferImage (scene.h:578-600), colorArray (Main.cpp:219-229) */
+int oracle_first_hit(const void *blob, int math_mode, float *z, float *normal, float *albedo);
+int oracle_zbuffer_image(const float *zbuffer, size_t size, uint8_t *zbufferImg);
+int oracle_color_image(const float *radiance, size_t n_floats, int gamma, int math_mode, float *color);
 /* global photon map, BuildPhotonMap (Main.cpp:251-317, MtlBlinn.cpp:140-202): balanced + emission-order records (24 B each) */
 int oracle_photon_build_global(const void *blob, const oracle_opts *opts, uint32_t max_photons, void *photons_out, void *emitted_out,
                                uint32_t *n_stored, uint64_t *n_emitted);

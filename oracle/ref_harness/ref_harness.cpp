@@ -374,6 +374,37 @@ int main(int argc, char **argv)
                 }
             WriteFile(prefix + ".primary_i32", oi);
             WriteFile(prefix + ".primary_f32", of);
+        } else if (cmd == "aux") {
+            // the images RenderImage holds beside the colour: zbuffer as the commented-out store of Main.cpp:231 would fill it
+            // (HitInfo::z of the pixel's un-jittered ray), then the reference's own ComputeZBufferImage; plus the hit normal and
+            // diffuse.Sample(uvw, duvw) = the optional DenoiseImage inputs (Main.cpp:70-71)
+            renderImage.Init(W, H);
+            std::vector<float> nrm((size_t)W * H * 3, 0.f), alb((size_t)W * H * 3, 0.f);
+            for (int j = 0; j < H; j++)
+                for (int i = 0; i < W; i++) {
+                    Vec3f pixelCenter = topLeft + (i + 1 / 2) * dd_x - (j + 1 / 2) * dd_y;
+                    Ray ray = Ray(camera.pos, pixelCenter - camera.pos);
+                    bool bHit = false;
+                    HitInfo h = HitInfo();
+                    recursive(&rootNode, ray, h, bHit, HIT_FRONT);
+                    const size_t pix = (size_t)j * W + i;
+                    renderImage.GetZBuffer()[pix] = h.z;
+                    if (bHit) {
+                        nrm[pix * 3] = h.N.x; nrm[pix * 3 + 1] = h.N.y; nrm[pix * 3 + 2] = h.N.z;
+                        const Material *m = h.node->GetMaterial();
+                        Color kd = Color::Black();
+                        if (const MtlBlinn *b = dynamic_cast<const MtlBlinn *>(m)) kd = b->diffuse.Sample(h.uvw, h.duvw);
+                        else if (m) kd = Color::White(); // MultiMtl::Shade of an empty list, materials.h:71
+                        alb[pix * 3] = kd.r; alb[pix * 3 + 1] = kd.g; alb[pix * 3 + 2] = kd.b;
+                    }
+                }
+            std::vector<float> zb(renderImage.GetZBuffer(), renderImage.GetZBuffer() + (size_t)W * H);
+            renderImage.ComputeZBufferImage();
+            std::vector<unsigned char> zi(renderImage.GetZBufferImage(), renderImage.GetZBufferImage() + (size_t)W * H);
+            WriteFile(prefix + ".aux_z_f32", zb);
+            WriteFile(prefix + ".aux_zimg_u8", zi);
+            WriteFile(prefix + ".aux_normal_f32", nrm);
+            WriteFile(prefix + ".aux_albedo_f32", alb);
         } else if (cmd == "rays") {
             std::vector<float> in = ReadFile<float>(raysFile); // N x 7: o, d, hitSide
             std::vector<int> oi; std::vector<float> of;
@@ -438,6 +469,7 @@ int main(int argc, char **argv)
             std::vector<float> samples((size_t)rw * rh * spp * 3);
             std::vector<float> radiance((size_t)rw * rh * 3);
             std::vector<unsigned char> rgb((size_t)rw * rh * 3);
+            std::vector<float> colorArray((size_t)rw * rh * 3); // Main.cpp:202,229: what DenoiseImage is given
             std::vector<unsigned> draws((size_t)rw * rh * spp);
             const float pixelLen = dd_x.Length();
             for (int j = ry0; j < ry1; j++)
@@ -470,12 +502,14 @@ int main(int argc, char **argv)
                     g.r = pow(outColor.r, inverseGama);
                     g.g = pow(outColor.g, inverseGama);
                     g.b = pow(outColor.b, inverseGama);
+                    colorArray[pix * 3 + 0] = g.r; colorArray[pix * 3 + 1] = g.g; colorArray[pix * 3 + 2] = g.b;
                     Color24 q = Color24(g); // Main.cpp:230
                     rgb[pix * 3 + 0] = q.r; rgb[pix * 3 + 1] = q.g; rgb[pix * 3 + 2] = q.b;
                 }
             WriteFile(prefix + ".samples_f32", samples);
             WriteFile(prefix + ".radiance_f32", radiance);
             WriteFile(prefix + ".rgb8", rgb);
+            WriteFile(prefix + ".color_f32", colorArray);
             WriteFile(prefix + ".draws_u32", draws);
         } else {
             usage();

@@ -14,7 +14,9 @@ The reference has no tests or golden vectors of its own, s
   c5_caustics_photon  caustic photon map: emission, balance, gathers, radiance with the caustic term
   global_photon       the global photon map (BuildPhotonMap, Main.cpp:251-317) of several scenes
 
-`make_golden.py global_photon` regenerates only the last one.
+  aux_images          RenderImage's z-buffer + ComputeZBufferImage, first-hit normal / albedo, colorArray (post-gamma floats)
+
+`make_golden.py global_photon` / `make_golden.py aux_images` regenerate only that file.
 """
 import hashlib
 import os
@@ -59,8 +61,8 @@ def main():
     if not os.path.exists(HARNESS):
         sys.exit("oracle/_ref/ref_harness missing: run `make -C oracle ref` in the development container")
     tmp = tempfile.mkdtemp(prefix="bhrt_golden_")
-    if sys.argv[1:] == ["global_photon"]:
-        global_photon_case(tmp)
+    if sys.argv[1:] in (["global_photon"], ["aux_images"]):
+        {"global_photon": global_photon_case, "aux_images": aux_case}[sys.argv[1]](tmp)
         subprocess.run(["rm", "-rf", tmp])
         return
     for name, (xml, region, spp, gi) in CASES.items():
@@ -120,6 +122,7 @@ def main():
         print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {int((pi[..., 0] >= 0).sum())}/{W * H} primary hits")
     photon_case(tmp)
     global_photon_case(tmp)
+    aux_case(tmp)
     subprocess.run(["rm", "-rf", tmp])
 
 
@@ -152,6 +155,30 @@ def photon_case(tmp):
     np.savez_compressed(path, **out)
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {out['stored']} photons from {out['emitted']} emissions, "
           f"{int((out['gather_out'][:, :3].sum(1) > 0).sum())}/{len(q)} queries lit")
+
+
+def aux_case(tmp):
+    """Images beside the colour image, from the reference's own code where it has any: RenderImage::ComputeZBufferImage run
+    on the z-buffer the commented-out store of Main.cpp:231 would fill; HitInfo::N and MtlBlinn's diffuse.Sample(uvw, duvw) of
+    the first hit (the optional DenoiseImage inputs, Main.cpp:70-71); colorArray (Main.cpp:202,229) of the render region."""
+    out = {}
+    for name, (xml, region, spp, gi) in CASES.items():
+        pre = os.path.join(tmp, "aux_" + name)
+        x0, y0, x1, y1 = region
+        run(xml, pre, "--spp", spp, "--gi", gi, "--region", x0, y0, x1, y1, "aux", "render")
+        z = np.fromfile(pre + ".aux_z_f32", np.float32)
+        nrm = np.fromfile(pre + ".aux_normal_f32", np.float32).reshape(-1, 3)
+        alb = np.fromfile(pre + ".aux_albedo_f32", np.float32).reshape(-1, 3)
+        out[name + "_z_sha"], out[name + "_normal_sha"], out[name + "_albedo_sha"] = sha(z), sha(nrm), sha(alb)
+        out[name + "_z_every7"], out[name + "_normal_every7"], out[name + "_albedo_every7"] = z[::7], nrm[::7], alb[::7]
+        out[name + "_zimg"] = np.fromfile(pre + ".aux_zimg_u8", np.uint8)
+        npx = (x1 - x0) * (y1 - y0)
+        out[name + "_color"] = np.fromfile(pre + ".color_f32", np.float32).reshape(npx, 3)
+        out[name + "_radiance"] = np.fromfile(pre + ".radiance_f32", np.float32).reshape(npx, 3)
+        print(f"aux_images/{name}: {int((z < 1e30).sum())}/{len(z)} pixels hit, z image range {out[name + '_zimg'].min()}..{out[name + '_zimg'].max()}")
+    path = os.path.join(HERE, "aux_images.npz")
+    np.savez_compressed(path, **out)
+    print(f"aux_images: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 GLOBAL_CASES = {"c5_caustics": 3000, "c2_glass_small": 2000, "c4_textured": 1500}

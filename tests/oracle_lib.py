@@ -114,6 +114,30 @@ def photon_build_global(blob: bytes, max_photons, seed=0, rng=RNG_KEYED, math=MA
     return out[: ns.value].copy(), em[: ns.value].copy(), int(ne.value)
 
 
+def first_hit(blob: bytes, width, height, math=MATH_DEVICE):
+    """First hit of every pixel's un-jittered camera ray: (z (H*W), normal (H*W,3), albedo (H*W,3))."""
+    n = width * height
+    z, nrm, alb = np.zeros(n, np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    _check(lib().oracle_first_hit(C.c_char_p(blob), int(math), _p(z), _p(nrm), _p(alb)))
+    return z, nrm, alb
+
+
+def zbuffer_image(z):
+    """RenderImage::ComputeZBufferImage (scene.h:578-600)."""
+    z = np.ascontiguousarray(z, np.float32)
+    img = np.zeros(z.size, np.uint8)
+    _check(lib().oracle_zbuffer_image(_p(z), C.c_size_t(z.size), _p(img)))
+    return img
+
+
+def color_image(radiance, gamma=1, math=MATH_DEVICE):
+    """colorArray of BeginRender (Main.cpp:219-229): pow(c, 1/2.2f) as floats."""
+    r = np.ascontiguousarray(radiance, np.float32)
+    out = np.zeros_like(r)
+    _check(lib().oracle_color_image(_p(r), C.c_size_t(r.size), int(gamma), int(math), _p(out)))
+    return out
+
+
 def photon_attach(balanced):
     a = np.ascontiguousarray(balanced, np.uint8)
     _check(lib().oracle_photon_attach(_p(a), a.shape[0]))
