@@ -67,6 +67,7 @@ EXPORTS = [
     "bhrt_photon_get", "bhrt_photon_export", "bhrt_photon_import", "bhrt_photon_build_global", "bhrt_save_png", "bhrt_math_eval_dev",
     "bhrt_tiles_block_bytes", "bhrt_tiles_pack_dev", "bhrt_tiles_unpack_dev",
     "bhrt_first_hit", "bhrt_first_hit_dev", "bhrt_zbuffer_image_dev", "bhrt_color_image_dev",
+    "bhrt_scene_load_xml_ex", "bhrt_bvh_build",
 ]
 
 
@@ -120,9 +121,10 @@ def _ptr(a):
 class Scene:
     """A loaded scene = the reference's LoadScene() globals behind one handle (Main.cpp:17-37,43)."""
 
-    def __init__(self, xml_path: str):
+    def __init__(self, xml_path: str, bvh_device: int = -1):
+        """bvh_device >= 0: mesh BVHs are built on that HIP device (bhrt_scene_load_xml_ex) instead of by the host front-end."""
         self._h = C.c_void_p()
-        _check(lib().bhrt_scene_load_xml(os.fsencode(xml_path), C.byref(self._h)))
+        _check(lib().bhrt_scene_load_xml_ex(os.fsencode(xml_path), int(bvh_device), C.byref(self._h)))
         self.info = Info()
         _check(lib().bhrt_scene_info(self._h, C.byref(self.info)))
         self._flat = None
@@ -285,6 +287,19 @@ def tiles_block_bytes(width: int, height: int, tile: int, world: int) -> int:
     f = lib().bhrt_tiles_block_bytes
     f.restype = C.c_size_t
     return int(f(width, height, tile, world))
+
+
+def bvh_build(vertices, faces, max_per_leaf=4, device=0):
+    """cyBVH::Build on the device (bhrt_bvh_build): returns (nodes (n+1, 8) uint32 words of bhrt_bvh_node incl. the unused
+    slot 0, element order (n_faces,) uint32, depth)."""
+    v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+    f = np.ascontiguousarray(faces, np.uint32).reshape(-1, 3)
+    nodes = np.zeros((2 * len(f) + 1, 8), np.uint32)
+    elems = np.zeros(len(f), np.uint32)
+    n, depth = C.c_uint32(0), C.c_uint32(0)
+    _check(lib().bhrt_bvh_build(_ptr(v), len(v), _ptr(f), len(f), int(max_per_leaf), int(device), _ptr(nodes), len(nodes), C.byref(n), _ptr(elems),
+                                C.byref(depth)))
+    return nodes[: n.value + 1].copy(), elems, depth.value
 
 
 def tiles_pack_dev(rgb8_ptr: int, radiance_ptr: int, width, height, tile, rank, world, block_ptr: int, stream: int = 0):

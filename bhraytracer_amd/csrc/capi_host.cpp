@@ -31,17 +31,19 @@ void bhrt_default_opts(bhrt_opts *o)
     o->samples_per_pass = 0;
 }
 
-int bhrt_scene_load_xml(const char *path, bhrt_scene **out)
+int bhrt_scene_load_xml(const char *path, bhrt_scene **out) { return bhrt_scene_load_xml_ex(path, -1, out); }
+
+int bhrt_scene_load_xml_ex(const char *path, int bvh_device, bhrt_scene **out)
 {
     if (!path || !out) { bhrt::SetError("bhrt_scene_load_xml: null argument"); return BHRT_ERR_ARG; }
     *out = nullptr;
     bhrt_scene *s = new bhrt_scene;
     std::string err;
-    int rc = bhrt::LoadSceneXml(path, s->flat, err);
+    int rc = bhrt::LoadSceneXml(path, s->flat, err, bvh_device);
     if (rc) {
         bhrt::SetError(err);
         delete s;
-        return rc == 1 ? BHRT_ERR_IO : BHRT_ERR_PARSE;
+        return rc == 1 ? BHRT_ERR_IO : (rc == 7 ? BHRT_ERR_HIP : BHRT_ERR_PARSE);
     }
     const bhrt_flat_header *H = s->flat.hdr();
     const bhrt_mesh *m = (const bhrt_mesh *)(s->flat.blob.data() + H->off_meshes);

@@ -23,6 +23,7 @@
 #include <map>
 #include <memory>
 
+#include "bhrt.h"
 #include "mini_xml.h"
 #include "png_io.h"
 #include "vecmath.h"
@@ -211,6 +212,8 @@ struct NodeData {
 };
 
 struct Loader {
+    int bvh_device = -1;
+    std::string fatal;
     std::string xml_dir;
     FlatScene *out;
     std::vector<NodeData> nodes;
@@ -441,7 +444,9 @@ struct Loader {
                         if (hm->vn.empty()) ComputeNormals(*hm);
                         ComputeBoundingBox(*hm);
                         if (!hm->had_vt) Warn("mesh \"" + key + "\" has no vt lines: the reference dereferences null here (SURVEY.md Q12); uvw = 0 is used");
-                        BuildBvh(*hm, 4);
+                        if (bvh_device >= 0) {
+                            if (BuildBvhDevice(*hm, 4, bvh_device) != 0 && fatal.empty()) fatal = "device BVH build of \"" + key + "\" failed: " + bhrt_last_error();
+                        } else BuildBvh(*hm, 4);
                         meshes.push_back(std::move(hm));
                         mi = (int)meshes.size() - 1;
                         mesh_by_name[key] = mi;
@@ -878,7 +883,7 @@ void BuildBvh(HostMesh &m, unsigned maxPer)
 // ------------------------------------------------------------------------------------------------
 // LoadSceneXml
 // ------------------------------------------------------------------------------------------------
-int LoadSceneXml(const char *path, FlatScene &out, std::string &err)
+int LoadSceneXml(const char *path, FlatScene &out, std::string &err, int bvh_device)
 {
     out.blob.clear();
     out.warnings.clear();
@@ -893,6 +898,7 @@ int LoadSceneXml(const char *path, FlatScene &out, std::string &err)
 
     Loader L;
     L.out = &out;
+    L.bvh_device = bvh_device;
     {
         std::string p = path;
         size_t slash = p.find_last_of("/\\");
@@ -961,6 +967,7 @@ int LoadSceneXml(const char *path, FlatScene &out, std::string &err)
     unsigned maxDepth = 0;
     for (auto &n : L.nodes) if ((unsigned)n.depth > maxDepth) maxDepth = (unsigned)n.depth;
     if (maxDepth > BHRT_MAX_NODE_DEPTH) { err = "scene graph deeper than BHRT_MAX_NODE_DEPTH"; return 6; }
+    if (!L.fatal.empty()) { err = L.fatal; return 7; }
 
     // ---------------- flatten
     std::vector<uint8_t> &blob = out.blob;

@@ -16,7 +16,8 @@ struct FlatScene {
 };
 
 // Returns 0 on success (like LoadScene returning 1), non-zero + err on failure.
-int LoadSceneXml(const char *path, FlatScene &out, std::string &err);
+// bvh_device >= 0: the mesh BVHs are built on that HIP device (bvh_build.hip) instead of by BuildBvh below; same result.
+int LoadSceneXml(const char *path, FlatScene &out, std::string &err, int bvh_device = -1);
 
 // OBJ mesh -> arrays, same face/index rules as cyTriMesh::LoadFromFileObj (cyTriMesh.h:263-547)
 struct HostMesh {
@@ -42,5 +43,6 @@ bool LoadObj(const char *path, bool load_mtl, HostMesh &m, std::string &err);
 void ComputeNormals(HostMesh &m);     // cyTriMesh.h:248-261
 void ComputeBoundingBox(HostMesh &m); // cyTriMesh.h:229-246
 void BuildBvh(HostMesh &m, unsigned max_elems_per_node = 4); // cyBVH.h:122-142, objects.h:59
+int BuildBvhDevice(HostMesh &m, unsigned max_elems_per_node, int device); // the same tree from the device build (bvh_build.hip); 0 = ok
 
 } // namespace bhrt

@@ -96,6 +96,16 @@ void bhrt_default_opts(bhrt_opts *opts);
 
 /* ---- scene (= LoadScene + the globals it fills) ------------------------------------------------ */
 int bhrt_scene_load_xml(const char *path, bhrt_scene **out);            /* xmlload.cpp:65 */
+/* same, with the mesh BVHs (TriObj::Load -> cyBVHTriMesh::SetMesh(this, 4), objects.h:59) built on HIP device `bvh_device`
+ * instead of by the host front-end; -1 = host.  The flattened scene is byte-identical either way. */
+int bhrt_scene_load_xml_ex(const char *path, int bvh_device, bhrt_scene **out);
+/* cyBVH::Build (DataStructure/cyBVH.h:122-142; SplitTempNode :242-278, ConvertTempData :281-291, MeanSplit :295-328) on the
+ * device, node for node: ids, boxes, leaf ranges and element order equal the reference's recursive build.  Host pointers.
+ * vertices: n_vertices xyz triples; faces: n_faces index triples; nodes_out (bhrt_bvh_node of include/bhrt_flat.h): capacity
+ * >= 2 * n_faces + 1 is always enough (node 0 unused, root = 1; *n_nodes = nodes without slot 0); elems_out: n_faces. */
+struct bhrt_bvh_node;
+int bhrt_bvh_build(const float *vertices, uint32_t n_vertices, const uint32_t *faces, uint32_t n_faces, uint32_t max_per_leaf, int device,
+                   struct bhrt_bvh_node *nodes_out, uint32_t node_capacity, uint32_t *n_nodes, uint32_t *elems_out, uint32_t *depth);
 void bhrt_scene_free(bhrt_scene *scene);
 int bhrt_scene_info(const bhrt_scene *scene, bhrt_info *info);
 int bhrt_scene_warning(const bhrt_scene *scene, uint32_t i, const char **text); /* the reference printf()s these */
