@@ -246,23 +246,45 @@ __device__ inline V3 sample_in_semi_sphere(DRng &g, V3 N, float &o_theta) // Mtl
     }
     return N;
 }
-// GIUseSpecularDirOrDiffuseDir, MtlBlinn.cpp:354-378
+// The draws and the lobe angle of GetSampleAlongLightDirection without the direction itself (see gi_direction)
+struct LobeDraw { float theta, phi; V3 rc; };
+__device__ inline LobeDraw draw_along_light_direction(DRng &g, V3 N, float glossiness)
+{
+    LobeDraw d;
+    const float u = g.rnd01();
+    d.theta = acos_safe(dm::powf_(u, 1.f / (glossiness + 1.f)));
+    d.phi = (float)(g.rnd01() * 2 * BHRT_PI_D);
+    d.rc = random_crossing_vector(g, N);
+    return d;
+}
+__device__ inline V3 build_along_light_direction(V3 N, const LobeDraw &d)
+{
+    const float R = dm::tanf_(d.theta);
+    const float x = R * dm::cosf_(d.phi), y = R * dm::sinf_(d.phi);
+    const V3 axis1 = cross(d.rc, N);
+    const V3 axis2 = cross(axis1, N);
+    return N + normalized(axis1) * x + normalized(axis2) * y;
+}
+// GIUseSpecularDirOrDiffuseDir, MtlBlinn.cpp:354-378.  The reference builds the diffuse and the specular candidate and keeps
+// one; the choice depends only on the two lobe angles and one more draw.  All draws are made in the reference's order, the
+// specular direction (tan, sin, cos, two normalisations) is only built when it is the one kept, the diffuse one (built anyway:
+// its rejection loop tests it) only normalised then: a wave of diffuse-surface hits skips ~300 instructions.
 __device__ inline V3 gi_direction(DRng &g, bool &useSpecular, V3 vN, V3 vV, float kd, float ks, float glossiness)
 {
     float diffuseTheta = 0;
-    V3 diffuseRayDir = normalized(sample_in_semi_sphere(g, vN, diffuseTheta));
+    const V3 diffuseRaw = sample_in_semi_sphere(g, vN, diffuseTheta);
     float p_diffuseTheta = dm::sinf_(2 * diffuseTheta);
-    float specularTheta = 0;
     float cosvVvN = dot(vN, vV);
     V3 vR = (2 * cosvVvN) * vN - vV;
-    V3 specRayDir = sample_along_light_direction(g, vR, glossiness, specularTheta);
-    float p_specularTheta = dm::powf_(dm::cosf_(specularTheta), glossiness);
+    const LobeDraw lobe = draw_along_light_direction(g, vR, glossiness);
+    float p_specularTheta = dm::powf_(dm::cosf_(lobe.theta), glossiness);
     float P_Diffuse = kd * p_diffuseTheta;
     float P_sum = P_Diffuse + ks * p_specularTheta;
     float P_Diffuse_Norm = P_Diffuse / P_sum;
     float rnd = g.rnd01();
     useSpecular = rnd >= P_Diffuse_Norm;
-    return useSpecular ? specRayDir : diffuseRayDir;
+    if (useSpecular) return build_along_light_direction(vR, lobe);
+    return normalized(diffuseRaw);
 }
 __device__ inline float tc_max(const float *c) { return fmax_cy(fmax_cy(c[0], c[1]), c[2]); } // GetKD/GetKS, MtlBlinn.cpp:68-69
 __device__ inline float gray3(const float *c) { return (c[0] + c[1] + c[2]) / 3.0f; }
@@ -282,7 +304,6 @@ __device__ inline V3 sample_in_light(DRng &g, const float *diffuseColor, const f
         const float Rd = dm::tanf_(diffuseTheta);
         const float phi_d = (float)(g.rnd01() * 2 * BHRT_PI_D);
         const V3 rc_d = random_crossing_vector(g, nL);
-        const float p_diffuse = dm::powf_(dm::cosf_(diffuseTheta), glossiness);
         bool useSpecular = false;
         float Rs = 0, theta_s = 0;
         V3 rc_s = v3(0, 0, 1);
@@ -295,6 +316,7 @@ __device__ inline V3 sample_in_light(DRng &g, const float *diffuseColor, const f
             const float p_specular = 2 * r / (Rs * Rs);
             if (ks != 0 && kd == 0) useSpecular = true;
             else {
+                const float p_diffuse = dm::powf_(dm::cosf_(diffuseTheta), glossiness); // no draws: evaluated only where the choice needs it
                 const float P_Diffuse = kd * p_diffuse;
                 const float P_Specular = ks * p_specular;
                 const float P_sum = P_Diffuse + P_Specular;
