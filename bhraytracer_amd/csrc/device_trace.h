@@ -77,33 +77,30 @@ __device__ inline bool box_hit(const float *b, V3 o, V3 d, float t_max, float &t
 // The same slab test for many boxes along ONE ray: the six IEEE float divisions per box become
 // float(double(a) * rd) with rd = 1.0 / double(d) computed once per ray and axis.  This is bit-identical to the
 // float division a / d: the quotient of two binary32 numbers is never closer than 2^-49 (relative) to a rounding
-// boundary (midpoint) of binary32, while double(a)*rd differs from a/d by at most 2^-52 (relative), so both round
-// to the same float.  The argument needs a normal, finite quotient; anything else takes the plain division.
+// boundary of binary32 (a midpoint between neighbours, or the overflow threshold), while double(a)*rd differs from a/d by
+// at most 2^-52 (relative), so both round to the same float — also to the same infinity.  The argument needs 24 bits of
+// quotient: a subnormal quotient takes the plain division (and so does an exact zero, which the one cheap test below cannot
+// tell from it), and so does a ray with a zero direction component, for which the reference does not divide at all.
+// (Per-quotient exponent checks instead of the one min-of-magnitudes test: 13 % more time in k_trace_mesh.)
 struct RayRcp {
     double rx, ry, rz;
+    bool slow; // a zero direction component: the reference replaces those quotients by +-BIGFLOAT (Box.cpp), plain form
 };
 __device__ inline RayRcp ray_rcp(V3 d)
 {
     RayRcp r;
     r.rx = 1.0 / (double)d.x; r.ry = 1.0 / (double)d.y; r.rz = 1.0 / (double)d.z;
+    r.slow = d.x == 0 || d.y == 0 || d.z == 0;
     return r;
-}
-// One quotient of the shared-reciprocal slab test and its validity: the exponent field must lie in [28, 226]
-// (2^-99 <= |q| < 2^100: a normal, finite, non-zero quotient).  Zero, subnormal, huge, inf and NaN quotients — which is
-// also what a zero direction component produces through rd = inf — send the WHOLE box to the plain-division form.
-__device__ inline float mul_shared(float a, double rd, uint32_t &bad)
-{
-    const float q = (float)((double)a * rd);
-    bad |= (((__float_as_uint(q) >> 23) & 0xffu) - 28u) > 198u ? 1u : 0u;
-    return q;
 }
 __device__ inline bool box_hit_rcp(const float *b, V3 o, V3 d, const RayRcp &r, float t_max, float &t_min)
 {
-    uint32_t bad = 0;
-    const float tz1 = mul_shared(b[2] - o.z, r.rz, bad), tz2 = mul_shared(b[5] - o.z, r.rz, bad);
-    const float ty1 = mul_shared(b[1] - o.y, r.ry, bad), ty2 = mul_shared(b[4] - o.y, r.ry, bad);
-    const float tx1 = mul_shared(b[0] - o.x, r.rx, bad), tx2 = mul_shared(b[3] - o.x, r.rx, bad);
-    if (bad) return box_hit(b, o, d, t_max, t_min); // rare: one branch per box instead of one per quotient
+    const float tz1 = (float)((double)(b[2] - o.z) * r.rz), tz2 = (float)((double)(b[5] - o.z) * r.rz);
+    const float ty1 = (float)((double)(b[1] - o.y) * r.ry), ty2 = (float)((double)(b[4] - o.y) * r.ry);
+    const float tx1 = (float)((double)(b[0] - o.x) * r.rx), tx2 = (float)((double)(b[3] - o.x) * r.rx);
+    // a zero or subnormal quotient (double rounding could differ there) sends the whole box to the plain divisions; one test
+    const float smallest = fminf(fminf(fminf(fabsf(tz1), fabsf(tz2)), fminf(fabsf(ty1), fabsf(ty2))), fminf(fabsf(tx1), fabsf(tx2)));
+    if (r.slow || !(smallest >= 1.17549435e-38f)) return box_hit(b, o, d, t_max, t_min);
     float tMin = fmax_cy(fmax_cy(fmin_cy(tx1, tx2), fmin_cy(ty1, ty2)), fmin_cy(tz1, tz2));
     float tMax = fmin_cy(fmin_cy(fmax_cy(tx1, tx2), fmax_cy(ty1, ty2)), fmax_cy(tz1, tz2));
     if (tMin <= tMax && tMin < t_max) { t_min = tMin; return true; }
