@@ -101,8 +101,10 @@ __device__ inline bool box_hit_rcp(const float *b, V3 o, V3 d, const RayRcp &r, 
     // a zero or subnormal quotient (double rounding could differ there) sends the whole box to the plain divisions; one test
     const float smallest = fminf(fminf(fminf(fabsf(tz1), fabsf(tz2)), fminf(fabsf(ty1), fabsf(ty2))), fminf(fabsf(tx1), fabsf(tx2)));
     if (r.slow || !(smallest >= 1.17549435e-38f)) return box_hit(b, o, d, t_max, t_min);
-    float tMin = fmax_cy(fmax_cy(fmin_cy(tx1, tx2), fmin_cy(ty1, ty2)), fmin_cy(tz1, tz2));
-    float tMax = fmin_cy(fmin_cy(fmax_cy(tx1, tx2), fmax_cy(ty1, ty2)), fmax_cy(tz1, tz2));
+    // no NaN and no zero among the six from here on: cyMin / cyMax (`a <= b ? a : b`, compare + select) and the hardware's
+    // min / max instructions give the same bits (they differ only on NaNs and on the sign of a zero)
+    const float tMin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+    const float tMax = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
     if (tMin <= tMax && tMin < t_max) { t_min = tMin; return true; }
     return false;
 }
