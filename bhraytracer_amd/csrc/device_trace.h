@@ -120,6 +120,51 @@ __device__ inline bool box_hit_rcp(const float *b, V3 o, V3 d, const RayRcp &r, 
     return false;
 }
 
+// Approximate-first slab test.  Every use of the slab test's results in the closest-hit traversal is a comparison
+// (tMin <= tMax, tMin < t_max, tmin of child 1 < tmin of child 2), so the six correctly rounded quotients are only needed when
+// a comparison is close.  q' = RN(a * RN(1/d)) is within 3 * 2^-24 (relative) of the rounded quotient RN(a/d) for normal
+// results; min / max keep that bound (two-sided, relative to the larger magnitude), so the approximate tMin / tMax are within
+// 2^-21 * |own value| (+ 2^-125 for subnormal quotients) of the exact ones.  A comparison is taken from the approximations
+// only when the two sides differ by more than 2^-19 * (|a| + |b|) + 2^-100 — 8x the bound, which also covers the rounding of
+// the difference and of the tolerance themselves; otherwise (and for rays with a zero direction component, whose quotients
+// the reference replaces by +-BIGFLOAT) the box is evaluated exactly (box_hit_rcp).  Infinite or NaN approximations make
+// |diff| > tol false, i.e. indecisive.  3 instructions per quotient become 1.
+#define BHRT_FAST_ABS 7.888609052210118e-31f /* 2^-100 */
+struct RayRcpF {
+    float rx, ry, rz;
+    bool slow;
+};
+__device__ inline RayRcpF ray_rcp_f(V3 d)
+{
+    RayRcpF r;
+    r.rx = 1.0f / d.x; r.ry = 1.0f / d.y; r.rz = 1.0f / d.z;
+    // zero components (see above), and components whose reciprocal would not be a normal float with full precision
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    r.slow = !(fminf(fminf(ax, ay), az) >= BHRT_FAST_ABS && fmaxf(fmaxf(ax, ay), az) <= 1.2676506e30f /* 2^100 */);
+    return r;
+}
+#define BHRT_FAST_REL 1.9073486328125e-06f /* 2^-19 */
+// 1 = hit, 0 = miss, -1 = too close to call.  One comparison decides both conditions: with u = min(tMax', t_max),
+// u - tMin' > tol means tMin < tMax and tMin < t_max for certain (tMax' >= u, and the error of tMax' relative to |u| is no
+// larger than relative to itself on the side that matters), u - tMin' < -tol means one of them fails for certain.
+__device__ inline int box_fast(const float *b, V3 o, const RayRcpF &r, float t_max, float &t_min_approx)
+{
+    const float tz1 = (b[2] - o.z) * r.rz, tz2 = (b[5] - o.z) * r.rz;
+    const float ty1 = (b[1] - o.y) * r.ry, ty2 = (b[4] - o.y) * r.ry;
+    const float tx1 = (b[0] - o.x) * r.rx, tx2 = (b[3] - o.x) * r.rx;
+    const float tMin = hw_max3(hw_min(tx1, tx2), hw_min(ty1, ty2), hw_min(tz1, tz2));
+    const float u = hw_min(hw_min3(hw_max(tx1, tx2), hw_max(ty1, ty2), hw_max(tz1, tz2)), t_max);
+    const float diff = u - tMin, tol = fmaf(BHRT_FAST_REL, fabsf(tMin) + fabsf(u), BHRT_FAST_ABS);
+    t_min_approx = tMin;
+    return diff > tol ? 1 : (diff < -tol ? 0 : -1);
+}
+// tmin1 < tmin2 from the approximations: 1 / 0, or -1 = too close to call
+__device__ inline int order_fast(float tmin1, float tmin2)
+{
+    const float d = tmin2 - tmin1, tol = fmaf(BHRT_FAST_REL, fabsf(tmin1) + fabsf(tmin2), BHRT_FAST_ABS);
+    return fabsf(d) > tol ? (d > 0 ? 1 : 0) : -1;
+}
+
 // barycentric part of IntersectTriangle (TriObj.cpp:105-168), shared with the attribute recomputation
 __device__ inline bool tri_areas(V3 v0, V3 v1, V3 v2, V3 vN, V3 vX, float &a0, float &a1, float &a2)
 {
@@ -234,9 +279,9 @@ __device__ inline uint32_t node_data(const MeshRef &M, uint32_t i) { return i < 
 __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront)
 {
     float tm;
-    const RayRcp rr = ray_rcp(d);
     const NodeRec root = node_at(M, 1);
-    if (!box_hit_rcp(root.b, o, d, rr, ht, tm)) return false;
+    if (!box_hit_rcp(root.b, o, d, ray_rcp(d), ht, tm)) return false;
+    const RayRcpF rf = ray_rcp_f(d);
     const float dlen = length(d);
     uint32_t cur = 1;
     int depth = 0;
@@ -254,15 +299,23 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
             NodeRec n1, n2;
             node_pair_at(M, c1, n1, n2);
             const uint32_t d1 = n1.data, d2 = n2.data;
-            bool b1 = box_hit_rcp(n1.b, o, d, rr, ht, tmin1);
-            bool b2 = box_hit_rcp(n2.b, o, d, rr, ht, tmin2);
+            const int f1 = rf.slow ? -1 : box_fast(n1.b, o, rf, ht, tmin1), f2 = rf.slow ? -1 : box_fast(n2.b, o, rf, ht, tmin2);
+            bool b1 = f1 == 1, b2 = f2 == 1;
+            int ord = (b1 && b2) ? order_fast(tmin1, tmin2) : (b1 ? 1 : 0);
+            if (f1 < 0 || f2 < 0 || ord < 0) { // a comparison too close to call (or a zero direction component): the exact test
+                const RayRcp rr = ray_rcp(d);
+                tmin1 = BHRT_BIGFLOAT; tmin2 = BHRT_BIGFLOAT;
+                b1 = box_hit_rcp(n1.b, o, d, rr, ht, tmin1);
+                b2 = box_hit_rcp(n2.b, o, d, rr, ht, tmin2);
+                ord = tmin1 < tmin2 ? 1 : 0;
+            }
             if (!b1 && !b2) { r = false; desc = false; }
             else {
                 depth++;
                 const uint64_t bit = 1ull << (depth - 1);
                 inFar &= ~bit;
                 nearHit &= ~bit;
-                const bool first1 = tmin1 < tmin2;
+                const bool first1 = ord == 1;
                 cur = first1 ? c1 : c1 + 1;
                 data = first1 ? d1 : d2;
             }
@@ -290,7 +343,9 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
                     float tmf;
                     const NodeRec ns = node_at(M, sib);
                     const uint32_t ds = ns.data;
-                    if (box_hit_rcp(ns.b, o, d, rr, ht, tmf)) { inFar |= bit; cur = sib; data = ds; desc = true; }
+                    int fs = rf.slow ? -1 : box_fast(ns.b, o, rf, ht, tmf);
+                    if (fs < 0) fs = box_hit_rcp(ns.b, o, d, ray_rcp(d), ht, tmf) ? 1 : 0;
+                    if (fs) { inFar |= bit; cur = sib; data = ds; desc = true; }
                     else { cur = node_parent(M, cur); depth--; /* r stays true */ }
                 } else {
                     inFar |= bit;

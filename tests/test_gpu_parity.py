@@ -94,6 +94,45 @@ def test_edge_cases(gpu, load_scene, O):
     assert np.array_equal(sc.trace_shadow(o, d, tm), O.trace_shadow(blob, o, d, tm))
 
 
+def test_rays_through_bvh_box_corners(gpu, B, O, tmp_path):
+    """The closest-hit traversal takes the slab comparisons from approximate quotients when they are decisive and evaluates a box
+    exactly otherwise (device_trace.h::box_fast).  Rays from one BVH box corner through another graze box faces, edges and
+    corners, which puts tMin ~ tMax and tmin(child 1) ~ tmin(child 2) within a few ulp: the hit records still have to equal
+    the oracle's bit for bit."""
+    import shutil
+    from conftest import SCENES
+    shutil.copy(os.path.join(SCENES, "mesh_small.obj"), tmp_path / "mesh_small.obj")
+    xml = tmp_path / "m.xml"
+    xml.write_text("""<xml><scene><object type="obj" name="mesh_small.obj" material="m"/>
+      <material type="blinn" name="m"/><light type="point" name="l"><intensity value="1"/><position z="9"/></light></scene>
+      <camera><position y="-9" z="1"/><target z="0"/><up z="1"/><width value="16"/><height value="16"/></camera></xml>""")
+    sc = B.Scene(str(xml))
+    v, f = [], []
+    for line in open(tmp_path / "mesh_small.obj"):
+        t = line.split()
+        if t and t[0] == "v":
+            v.append([float(x) for x in t[1:4]])
+        elif t and t[0] == "f":
+            f.append([int(x.split("/")[0]) - 1 for x in t[1:4]])
+    nodes, _, _ = B.bvh_build(np.float32(v), np.uint32(f))
+    boxes = nodes[1:, :6].copy().view(np.float32)
+    rng = np.random.default_rng(8)
+    corners = np.stack([np.where(rng.random((4000, 3)) < 0.5, boxes[rng.integers(0, len(boxes), 4000)][:, :3],
+                                 boxes[rng.integers(0, len(boxes), 4000)][:, 3:]) for _ in range(2)])
+    a, b = corners[0].astype(np.float32), corners[1].astype(np.float32)
+    keep = np.abs(b - a).min(axis=1) > 0
+    a, b = a[keep], b[keep]
+    d = (b - a).astype(np.float32)
+    o = (a - np.float32(3.0) * d).astype(np.float32)          # start outside, pass through both corners
+    blob = sc.flat_bytes()
+    for side in (1, 3):
+        h, r = sc.trace_closest(o, d, side), O.trace_closest(blob, o, d, side)
+        assert np.array_equal(h["node"], r["node"]) and np.array_equal(h["prim"], r["prim"]) and same_bits(h["t"], r["t"])
+    assert (r["node"] >= 0).sum() > len(o) // 10
+    tm = np.full(len(o), 10.0, np.float32)
+    assert np.array_equal(sc.trace_shadow(o, d, tm), O.trace_shadow(blob, o, d, tm))
+
+
 def test_nested_scene_graph_depth3(gpu, B, O, tmp_path):
     # recursive() back-transforms only through the hit node and its direct parent (Main.cpp:407-412, SURVEY.md Q6):
     # a depth-3 node leaves p/N in its grandparent's space; t and node index are what the tracer returns
