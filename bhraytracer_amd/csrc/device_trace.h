@@ -158,6 +158,17 @@ __device__ inline int box_fast(const float *b, V3 o, const RayRcpF &r, float t_m
     t_min_approx = tMin;
     return diff > tol ? 1 : (diff < -tol ? 0 : -1);
 }
+// the same for the any-hit loop, with fminf / fmaxf (see box_hit_rcp<false>: that loop schedules worse around the asm forms)
+__device__ inline int box_fast_f(const float *b, V3 o, const RayRcpF &r, float t_max)
+{
+    const float tz1 = (b[2] - o.z) * r.rz, tz2 = (b[5] - o.z) * r.rz;
+    const float ty1 = (b[1] - o.y) * r.ry, ty2 = (b[4] - o.y) * r.ry;
+    const float tx1 = (b[0] - o.x) * r.rx, tx2 = (b[3] - o.x) * r.rx;
+    const float tMin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+    const float u = fminf(fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2)), t_max);
+    const float diff = u - tMin, tol = fmaf(BHRT_FAST_REL, fabsf(tMin) + fabsf(u), BHRT_FAST_ABS);
+    return diff > tol ? 1 : (diff < -tol ? 0 : -1);
+}
 // tmin1 < tmin2 from the approximations: 1 / 0, or -1 = too close to call
 __device__ inline int order_fast(float tmin1, float tmin2)
 {
@@ -373,6 +384,7 @@ __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
     const RayRcp rr = ray_rcp(d);
     if (!box_hit_rcp<false>(node_at(M, 1).b, o, d, rr, BHRT_BIGFLOAT, tm)) return false;
     const float dlen = length(d);
+    const RayRcpF rf = ray_rcp_f(d);
     uint32_t cur = 1;
     int depth = 0;
     bool desc = true, found = false;
@@ -394,8 +406,10 @@ __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
                 const uint32_t c1 = data & 0x7fffffffu;
                 float t1, t2;
                 const NodeRec n1 = node_at(M, c1), n2 = node_at(M, c1 + 1);
-                bool b1 = box_hit_rcp<false>(n1.b, o, d, rr, BHRT_BIGFLOAT, t1);
-                bool b2 = box_hit_rcp<false>(n2.b, o, d, rr, BHRT_BIGFLOAT, t2);
+                int f1 = rf.slow ? -1 : box_fast_f(n1.b, o, rf, BHRT_BIGFLOAT), f2 = rf.slow ? -1 : box_fast_f(n2.b, o, rf, BHRT_BIGFLOAT);
+                if (f1 < 0) f1 = box_hit_rcp<false>(n1.b, o, d, rr, BHRT_BIGFLOAT, t1) ? 1 : 0;
+                if (f2 < 0) f2 = box_hit_rcp<false>(n2.b, o, d, rr, BHRT_BIGFLOAT, t2) ? 1 : 0;
+                const bool b1 = f1 == 1, b2 = f2 == 1;
                 if (!b1 && !b2) desc = false;
                 else { depth++; cur = c1; }
             }
