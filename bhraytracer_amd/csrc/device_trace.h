@@ -375,6 +375,98 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
     return any;
 }
 
+// The same traversal with the path kept in LDS: stack[level * stride] holds the pair index (id >> 1) of the level's
+// first-visited child, `side` its low id bit.  Returning from a second-visited child only passes the result up, so the climb
+// jumps straight to the deepest level still waiting in its first-visited child (a bit scan over inFar) instead of walking
+// parent links one dependent load at a time.  Needs ids < 2^17 and depth <= 32 (the caller checks the mesh).
+__device__ inline bool mesh_closest_stack(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront, uint16_t *stack, uint32_t stride)
+{
+    float tm;
+    const NodeRec root = node_at(M, 1);
+    if (!box_hit_rcp(root.b, o, d, ray_rcp(d), ht, tm)) return false;
+    const RayRcpF rf = ray_rcp_f(d);
+    const float dlen = length(d);
+    uint32_t cur = 1;
+    int depth = 0;
+    uint32_t inFar = 0, nearHit = 0, sides = 0;
+    bool desc = true, r = false, any = false;
+    uint32_t data = root.data;
+    while (true) {
+        // ---- phase 1: descend through inner nodes
+        while (desc && !(data & 0x80000000u)) {
+            const uint32_t c1 = data & 0x7fffffffu;
+            float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
+            NodeRec n1, n2;
+            node_pair_at(M, c1, n1, n2);
+            const uint32_t d1 = n1.data, d2 = n2.data;
+            const int f1 = rf.slow ? -1 : box_fast(n1.b, o, rf, ht, tmin1), f2 = rf.slow ? -1 : box_fast(n2.b, o, rf, ht, tmin2);
+            bool b1 = f1 == 1, b2 = f2 == 1;
+            int ord = (b1 && b2) ? order_fast(tmin1, tmin2) : (b1 ? 1 : 0);
+            if (f1 < 0 || f2 < 0 || ord < 0) {
+                const RayRcp rr = ray_rcp(d);
+                tmin1 = BHRT_BIGFLOAT; tmin2 = BHRT_BIGFLOAT;
+                b1 = box_hit_rcp(n1.b, o, d, rr, ht, tmin1);
+                b2 = box_hit_rcp(n2.b, o, d, rr, ht, tmin2);
+                ord = tmin1 < tmin2 ? 1 : 0;
+            }
+            if (!b1 && !b2) { r = false; desc = false; }
+            else {
+                depth++;
+                const uint32_t bit = 1u << (depth - 1);
+                inFar &= ~bit;
+                nearHit &= ~bit;
+                const bool first1 = ord == 1;
+                cur = first1 ? c1 : c1 + 1;
+                data = first1 ? d1 : d2;
+                sides = first1 ? (sides & ~bit) : (sides | bit);
+                stack[(uint32_t)depth * stride] = (uint16_t)(c1 >> 1);
+            }
+        }
+        // ---- phase 2: leaf
+        if (desc) {
+            const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
+            r = false;
+            for (uint32_t i = 0; i < count; i++) {
+                const bhrt_tri &tr = M.ltris[off + i];
+                float t;
+                int fr;
+                if (tri_hit(tr, o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)tr.face; hfront = fr; r = true; }
+            }
+            any |= r;
+            desc = false;
+        }
+        // ---- phase 3: up to the deepest level whose first-visited child has just returned
+        while (!desc && depth > 0) {
+            const uint32_t below = depth >= 32 ? 0xffffffffu : ((1u << depth) - 1u); // levels 1..depth
+            const uint32_t waiting = ~inFar & below;
+            if (!waiting) { depth = 0; break; } // every level is in its second child: the root call returns
+            const int l = 32 - __clz((int)waiting); // that level
+            const uint32_t upto = l >= 32 ? 0xffffffffu : ((1u << l) - 1u);
+            r = r || (nearHit & below & ~upto) != 0; // `first child's r ? true : r` of the levels passed
+            depth = l;
+            const uint32_t bit = 1u << (l - 1);
+            const uint32_t sib = ((uint32_t)stack[(uint32_t)l * stride] << 1) | (((sides >> (l - 1)) & 1u) ^ 1u);
+            if (r) {
+                nearHit |= bit;
+                float tmf;
+                const NodeRec ns = node_at(M, sib);
+                const uint32_t ds = ns.data;
+                int fs = rf.slow ? -1 : box_fast(ns.b, o, rf, ht, tmf);
+                if (fs < 0) fs = box_hit_rcp(ns.b, o, d, ray_rcp(d), ht, tmf) ? 1 : 0;
+                if (fs) { inFar |= bit; cur = sib; data = ds; desc = true; }
+                else depth--; // r stays true
+            } else {
+                inFar |= bit;
+                cur = sib;
+                data = node_data(M, sib);
+                desc = true;
+            }
+        }
+        if (!desc) break;
+    }
+    return any;
+}
+
 // TriObj::ShadowRecursive + TraceBVHShadow (TriObj.cpp:41-66,272-307): pre-order walk (child1 then child2 — the
 // evaluation order of `A | B` in the g++ build of the reference), both children visited unless NEITHER box is hit,
 // stops at the first leaf that reports a front-face hit; the range test is applied to that hit only.
@@ -473,11 +565,11 @@ __device__ inline bool plane_hit(V3 p, V3 d, int side, float t_cur, float &t_out
 #ifndef BHRT_LDS_NODES
 #define BHRT_LDS_NODES 512 /* 16 KB per workgroup: 9 full levels */
 #endif
-__device__ inline void stage_nodelet(const DevScene &S, int mesh, bhrt_bvh_node *lds, MeshRef &M)
+__device__ inline void stage_nodelet(const DevScene &S, int mesh, bhrt_bvh_node *lds, MeshRef &M, uint32_t lds_nodes = BHRT_LDS_NODES /* even */)
 {
     M = mesh_ref(S, mesh);
     const uint32_t nn = S.meshes[mesh].n_bvh_nodes;
-    const uint32_t cnt = nn < BHRT_LDS_NODES ? nn : BHRT_LDS_NODES;
+    const uint32_t cnt = nn < lds_nodes ? nn : lds_nodes;
     __syncthreads(); // previous mesh's nodelet no longer in use
     const float4 *src = (const float4 *)M.bvh;
     float4 *dst = (float4 *)lds;
@@ -500,8 +592,11 @@ __device__ inline uint32_t park_spread(uint32_t v) // 5 bits -> every third bit
     v = (v | (v << 2)) & 0x00001249u;
     return v;
 }
+// path != nullptr: this lane's column of the LDS path stack (stride path_stride, 33 rows) -> mesh_closest_stack; the caller has
+// checked that every mesh qualifies.  lds_nodes: size of the nodelet buffer behind `lds`.
 __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit &h, bool active = true, bhrt_bvh_node *lds = nullptr, int start = 0,
-                                    bool park = false, uint32_t *park_key = nullptr)
+                                    bool park = false, uint32_t *park_key = nullptr, uint16_t *path = nullptr, uint32_t path_stride = 0,
+                                    uint32_t lds_nodes = BHRT_LDS_NODES)
 {
     if (start == 0) { h.t = BHRT_BIGFLOAT; h.node = -1; h.prim = -1; h.front = 1; }
     int parked = -1;
@@ -510,7 +605,7 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
         if (type == BHRT_OBJ_NONE) continue;
         MeshRef M;
         if (type == BHRT_OBJ_MESH) {
-            if (lds) stage_nodelet(S, S.nodes[n].mesh, lds, M);
+            if (lds) stage_nodelet(S, S.nodes[n].mesh, lds, M, lds_nodes);
             else M = mesh_ref(S, S.nodes[n].mesh);
         }
         if (!active || n < start || parked >= 0) continue;
@@ -538,7 +633,7 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
                 }
             }
         } else {
-            if (mesh_closest(M, lp, ld, side, h.t, h.prim, h.front)) h.node = n;
+            if (path ? mesh_closest_stack(M, lp, ld, side, h.t, h.prim, h.front, path, path_stride) : mesh_closest(M, lp, ld, side, h.t, h.prim, h.front)) h.node = n;
         }
     }
     return parked;

@@ -315,10 +315,15 @@ __global__ void __launch_bounds__(kBlock) k_park_scatter(RayOrder ord)
 // The parked rays in key order, one dense workgroup per kBlock of them: resume at the mesh node, finish the scene
 // graph, file the ray under its shading class (shard = workgroup mod 32: k_trace_closest left room for that, see
 // EnsureWorkspace).
-template <bool kCamera>
-__global__ void __launch_bounds__(kBlock) k_trace_mesh(DevScene S, PassInfo P, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
+// kPath: the traversal keeps its path in LDS (mesh_closest_stack; every mesh has ids < 2^17 and depth <= 32 — the host checks).
+// Six waves per SIMD: the kernel waits on dependent node fetches with 8 of 64 lanes busy; more waves in flight are worth the
+// few spilled registers (5 -> 6 waves: -4 %; 7: no further gain), so the nodelet is 256 nodes here (8 KB + 17 KB of path).
+constexpr uint32_t kMeshNodelet = 256;
+template <bool kCamera, bool kPath>
+__global__ void __launch_bounds__(kBlock, 6) k_trace_mesh(DevScene S, PassInfo P, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
 {
-    __shared__ bhrt_bvh_node nodelet[BHRT_LDS_NODES];
+    __shared__ bhrt_bvh_node nodelet[kMeshNodelet];
+    __shared__ uint16_t path[kPath ? 33 * kBlock : 1];
     const uint32_t total = ord.mesh_count[BHRT_ORDER_SHARDS];
     if (blockIdx.x * kBlock >= total) return; // uniform per workgroup
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
@@ -335,7 +340,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_mesh(DevScene S, PassInfo P, R
         hit.front = fw & 0xff;
         start = (fw >> 8) - 1;
     }
-    trace_closest(S, o, d, (int)((meta >> 4) & 3u), hit, active, nodelet, active ? start : S.n_nodes, false);
+    trace_closest(S, o, d, (int)((meta >> 4) & 3u), hit, active, nodelet, active ? start : S.n_nodes, false, nullptr, kPath ? path + threadIdx.x : nullptr, kBlock, kMeshNodelet);
     if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; }
     file_ray(active ? shading_class(meta, hit) : (uint32_t)RC_NONE, i, blockIdx.x & (BHRT_ORDER_SHARDS - 1), ord, cnt);
 }
@@ -1566,6 +1571,11 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
     if (pass_samples < (uint32_t)o.spp) pass_samples = (uint32_t)o.spp;
     const uint32_t frames_per_sample = 6; // Shade() frames per camera sample; an overflow halves the pass and retries
     D->timers = o.timers;
+    bool path_ok = true; // k_trace_mesh's LDS path stack: 16-bit pair indices, 32 levels
+    {
+        const bhrt_mesh *hm = (const bhrt_mesh *)(scene->flat.blob.data() + H->off_meshes);
+        for (uint32_t k = 0; k < H->n_meshes; k++) path_ok = path_ok && hm[k].n_bvh_nodes <= (1u << 17) && hm[k].bvh_depth <= 32;
+    }
     RenderParams R;
     R.internal_bounces = o.internal_bounces; R.gi_bounces = o.gi_bounces; R.photon = o.photon_map;
     auto wall0 = std::chrono::steady_clock::now();
@@ -1621,8 +1631,8 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, D->stream, RO.park_bucket + n_buckets, n_tiles);
                     hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, RO.park_bucket, n_buckets, RO.park_bucket + n_buckets);
                     hipLaunchKernelGGL(k_park_scatter, pg, tb, 0, D->stream, RO);
-                    if (first_step) hipLaunchKernelGGL(k_trace_mesh<true>, tg, tb, 0, D->stream, D->S, P, Q[cur], HB, RO, D->d_cnt);
-                    else hipLaunchKernelGGL(k_trace_mesh<false>, tg, tb, 0, D->stream, D->S, P, Q[cur], HB, RO, D->d_cnt);
+                    auto mesh_kernel = first_step ? (path_ok ? k_trace_mesh<true, true> : k_trace_mesh<true, false>) : (path_ok ? k_trace_mesh<false, true> : k_trace_mesh<false, false>);
+                    hipLaunchKernelGGL(mesh_kernel, tg, tb, 0, D->stream, D->S, P, Q[cur], HB, RO, D->d_cnt);
                 } else if (first_step) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, true>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
                 t.Stop();

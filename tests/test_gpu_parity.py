@@ -133,6 +133,39 @@ def test_rays_through_bvh_box_corners(gpu, B, O, tmp_path):
     assert np.array_equal(sc.trace_shadow(o, d, tm), O.trace_shadow(blob, o, d, tm))
 
 
+def test_deep_bvh_takes_the_parent_link_traversal(gpu, B, O, tmp_path):
+    """k_trace_mesh keeps the traversal path in LDS when every mesh has at most 32 BVH levels (and ids below 2^17) and walks
+    parent links otherwise.  Triangles at exponentially spaced positions make MeanSplit peel off two at a time: 48 levels."""
+    n = 100
+    with open(tmp_path / "chain.obj", "w") as fp:
+        for k in range(n):
+            x = 1.6 ** k * 1e-6
+            fp.write(f"v {x!r} -0.3 {0.2 + 0.001 * k!r}\nv {x * 1.05!r} 0.3 {0.2!r}\nv {x!r} 0.0 {0.6 + 0.002 * k!r}\n")
+        fp.write("vt 0 0 0\nvn 0 -1 0\n")
+        for k in range(n):
+            fp.write(f"f {3 * k + 1}/1/1 {3 * k + 2}/1/1 {3 * k + 3}/1/1\n")
+    xml = tmp_path / "deep_bvh.xml"
+    xml.write_text("""<xml><scene><background r="0.1" g="0.1" b="0.2"/><environment r="0.5" g="0.5" b="0.5"/>
+      <object type="plane" name="g" material="g"><scale value="50"/></object>
+      <object type="obj" name="chain.obj" material="m"><scale x="0.00002" y="8" z="8"/><translate x="-6"/></object>
+      <object type="sphere" name="s" material="m"><translate x="3" z="1"/></object>
+      <material type="blinn" name="g"><diffuse r="0.7" g="0.7" b="0.7"/><specular value="0"/></material>
+      <material type="blinn" name="m"><diffuse r="0.8" g="0.3" b="0.2"/><specular value="0.4"/><glossiness value="30"/></material>
+      <light type="point" name="l"><intensity value="200"/><position x="2" y="-8" z="12"/><size value="1"/></light></scene>
+      <camera><position x="0" y="-22" z="6"/><target x="0" y="0" z="2"/><up z="1"/><fov value="50"/><width value="128"/><height value="72"/></camera></xml>""")
+    sc = B.Scene(str(xml))
+    assert sc.info.max_bvh_depth > 32
+    blob = sc.flat_bytes()
+    gs, st = sc.render_samples(B.default_opts(spp=2, gi_bounces=2, seed=4), 0, 0, sc.width, sc.height)
+    ro = O.render(blob, sc.width, sc.height, 2, gi=2, seed=4)["samples"]
+    assert same_bits(gs, ro)
+    z, _, _ = sc.first_hit()
+    mesh_px = (O.first_hit(blob, sc.width, sc.height)[0].reshape(z.shape) == z).all()
+    assert mesh_px and (z < 1e30).any()
+    dev = B.Scene(str(xml), bvh_device=0)                       # the device build on a 48-level tree
+    assert dev.flat_bytes() == blob
+
+
 def test_nested_scene_graph_depth3(gpu, B, O, tmp_path):
     # recursive() back-transforms only through the hit node and its direct parent (Main.cpp:407-412, SURVEY.md Q6):
     # a depth-3 node leaves p/N in its grandparent's space; t and node index are what the tracer returns
