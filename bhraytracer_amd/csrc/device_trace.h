@@ -514,6 +514,60 @@ __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
     return found && t_min > BHRT_TRI_BIAS && t_min < t_max;
 }
 
+// mesh_shadow with the path in LDS (see mesh_closest_stack): after a subtree the walk continues at the second child of the
+// deepest level still in its first child, found by a bit scan; no parent links are read.
+__device__ inline bool mesh_shadow_stack(const MeshRef &M, V3 o, V3 d, float t_max, uint16_t *stack, uint32_t stride)
+{
+    float tm;
+    const RayRcp rr = ray_rcp(d);
+    if (!box_hit_rcp<false>(node_at(M, 1).b, o, d, rr, BHRT_BIGFLOAT, tm)) return false;
+    const float dlen = length(d);
+    const RayRcpF rf = ray_rcp_f(d);
+    uint32_t cur = 1, inSecond = 0;
+    int depth = 0;
+    bool desc = true, found = false;
+    float t_min = BHRT_BIGFLOAT;
+    while (true) {
+        if (desc) {
+            const uint32_t data = node_data(M, cur);
+            if (data & 0x80000000u) {
+                const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
+                float ht = BHRT_BIGFLOAT;
+                for (uint32_t i = 0; i < count; i++) {
+                    float t;
+                    int fr;
+                    if (tri_hit(M.ltris[off + i], o, d, dlen, BHRT_HIT_FRONT, ht, t, fr)) { ht = t; found = true; t_min = t; }
+                }
+                if (found) break;
+                desc = false;
+            } else {
+                const uint32_t c1 = data & 0x7fffffffu;
+                float t1, t2;
+                const NodeRec n1 = node_at(M, c1), n2 = node_at(M, c1 + 1);
+                int f1 = rf.slow ? -1 : box_fast_f(n1.b, o, rf, BHRT_BIGFLOAT), f2 = rf.slow ? -1 : box_fast_f(n2.b, o, rf, BHRT_BIGFLOAT);
+                if (f1 < 0) f1 = box_hit_rcp<false>(n1.b, o, d, rr, BHRT_BIGFLOAT, t1) ? 1 : 0;
+                if (f2 < 0) f2 = box_hit_rcp<false>(n2.b, o, d, rr, BHRT_BIGFLOAT, t2) ? 1 : 0;
+                if (f1 != 1 && f2 != 1) desc = false;
+                else {
+                    depth++;
+                    inSecond &= ~(1u << (depth - 1));
+                    stack[(uint32_t)depth * stride] = (uint16_t)(c1 >> 1);
+                    cur = c1;
+                }
+            }
+        } else {
+            const uint32_t below = depth >= 32 ? 0xffffffffu : ((1u << depth) - 1u);
+            const uint32_t waiting = ~inSecond & below;
+            if (!waiting) break;
+            depth = 32 - __clz((int)waiting);
+            inSecond |= 1u << (depth - 1);
+            cur = ((uint32_t)stack[(uint32_t)depth * stride] << 1) | 1u;
+            desc = true;
+        }
+    }
+    return found && t_min > BHRT_TRI_BIAS && t_min < t_max;
+}
+
 // Sphere::IntersectRay accept decision (Sphere.cpp:8-50)
 __device__ inline bool sphere_hit(V3 oc, V3 dir, int side, float t_cur, float &t_out, int &front_out)
 {
@@ -644,7 +698,7 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
 // kMode 0: everything.  kMode 1: spheres and planes only; returns 2.f instead of 1.f when the ray also hits the root
 // box of a mesh (the caller parks it for k_shadow_mesh).  kMode 2: the meshes only.
 template <int kMode>
-__device__ inline float trace_shadow_t(const DevScene &S, V3 o, V3 d, float t_max)
+__device__ inline float trace_shadow_t(const DevScene &S, V3 o, V3 d, float t_max, uint16_t *path = nullptr, uint32_t path_stride = 0)
 {
     V3 rp = o, rd = d;
     to_node_identity(rp, rd); // rootNode's own ToNodeCoords
@@ -682,7 +736,7 @@ __device__ inline float trace_shadow_t(const DevScene &S, V3 o, V3 d, float t_ma
             float tm; // the root box gate of TriObj::ShadowRecursive (TriObj.cpp:41-54), repeated by mesh_shadow
             if (!wants_mesh && box_hit_rcp<false>(node_at(mesh_ref(S, S.nodes[n].mesh), 1).b, lp, ld, ray_rcp(ld), BHRT_BIGFLOAT, tm)) wants_mesh = true;
         } else {
-            if (mesh_shadow(mesh_ref(S, S.nodes[n].mesh), lp, ld, t_max)) return 0.f;
+            if (path ? mesh_shadow_stack(mesh_ref(S, S.nodes[n].mesh), lp, ld, t_max, path, path_stride) : mesh_shadow(mesh_ref(S, S.nodes[n].mesh), lp, ld, t_max)) return 0.f;
         }
     }
     return wants_mesh ? 2.f : 1.f;

@@ -371,13 +371,15 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow_park(DevScene S, Shadow
     }
     file_ray(v == 2.f ? (uint32_t)RC_MESH : (uint32_t)RC_NONE, i, (i >> 10) & (BHRT_ORDER_SHARDS - 1), ord, cnt);
 }
+template <bool kPath> // kPath: traversal path in LDS (mesh_shadow_stack), same condition as k_trace_mesh
 __global__ void __launch_bounds__(kBlock) k_shadow_mesh(DevScene S, ShadowQueue q, float *vis, RayOrder ord)
 {
     __shared__ uint32_t s_seg;
+    __shared__ uint16_t path[kPath ? 33 * kBlock : 1];
     uint32_t i;
     if (!parked_entry(ord, blockIdx.x, &s_seg, i)) return;
     if (i == 0xffffffffu) return;
-    vis[q.frame[i]] = trace_shadow_t<2>(S, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), q.tmax[i]);
+    vis[q.frame[i]] = trace_shadow_t<2>(S, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), q.tmax[i], kPath ? path + threadIdx.x : nullptr, kBlock);
 }
 
 // segment table of the parked mesh rays for k_trace_mesh: 32 shards, one lane each
@@ -1657,7 +1659,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 if (H->n_meshes > 0) {
                     hipLaunchKernelGGL(k_trace_shadow_park, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis, RO, D->d_cnt);
                     hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
-                    hipLaunchKernelGGL(k_shadow_mesh, dim3(hg.x + BHRT_ORDER_SHARDS), hb, 0, D->stream, D->S, SQ, F.vis, RO);
+                    hipLaunchKernelGGL(path_ok ? k_shadow_mesh<true> : k_shadow_mesh<false>, dim3(hg.x + BHRT_ORDER_SHARDS), hb, 0, D->stream, D->S, SQ, F.vis, RO);
                 } else hipLaunchKernelGGL(k_trace_shadow, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis);
                 t.Stop();
             }
