@@ -646,8 +646,11 @@ __device__ inline uint32_t park_spread(uint32_t v) // 5 bits -> every third bit
     v = (v | (v << 2)) & 0x00001249u;
     return v;
 }
+// kMeshes = false: the scene has no mesh node; the BVH code is not compiled in (half the registers: 8 waves per SIMD instead of
+// 5, C2 trace 1.13 -> 0.90 ms).
 // path != nullptr: this lane's column of the LDS path stack (stride path_stride, 33 rows) -> mesh_closest_stack; the caller has
 // checked that every mesh qualifies.  lds_nodes: size of the nodelet buffer behind `lds`.
+template <bool kMeshes = true>
 __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit &h, bool active = true, bhrt_bvh_node *lds = nullptr, int start = 0,
                                     bool park = false, uint32_t *park_key = nullptr, uint16_t *path = nullptr, uint32_t path_stride = 0,
                                     uint32_t lds_nodes = BHRT_LDS_NODES)
@@ -657,8 +660,9 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
     for (int n = 0; n < S.n_nodes; n++) {
         const int type = S.nodes[n].obj_type;
         if (type == BHRT_OBJ_NONE) continue;
+        if (!kMeshes && type == BHRT_OBJ_MESH) continue; // cannot happen: the host picks kMeshes from the scene
         MeshRef M;
-        if (type == BHRT_OBJ_MESH) {
+        if (kMeshes && type == BHRT_OBJ_MESH) {
             if (lds) stage_nodelet(S, S.nodes[n].mesh, lds, M, lds_nodes);
             else M = mesh_ref(S, S.nodes[n].mesh);
         }
@@ -671,6 +675,7 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
             if (sphere_hit(lp, ld, side, h.t, t, fr)) { h.t = t; h.node = n; h.prim = -1; h.front = fr; }
         } else if (type == BHRT_OBJ_PLANE) {
             if (plane_hit(lp, ld, side, h.t, t, fr)) { h.t = t; h.node = n; h.prim = -1; h.front = fr; }
+        } else if (!kMeshes) {
         } else if (park) {
             float tm; // the root box gate of TriObj::IntersectRay (TriObj.cpp:17-39), repeated by mesh_closest on resume
             const NodeRec root = node_at(M, 1);
@@ -695,7 +700,7 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
 
 // GenLight::Shadow (GenLight.cpp:10-69).  The result is an OR over per-node tests that do not influence each
 // other, so nodes are tested in index order; each test is the reference's (including its quirks Q1-Q3).
-// kMode 0: everything.  kMode 1: spheres and planes only; returns 2.f instead of 1.f when the ray also hits the root
+// kMode 3: the scene has no mesh (BVH code not compiled in).  kMode 0: everything.  kMode 1: spheres and planes only; returns 2.f instead of 1.f when the ray also hits the root
 // box of a mesh (the caller parks it for k_shadow_mesh).  kMode 2: the meshes only.
 template <int kMode>
 __device__ inline float trace_shadow_t(const DevScene &S, V3 o, V3 d, float t_max, uint16_t *path = nullptr, uint32_t path_stride = 0)
@@ -707,6 +712,7 @@ __device__ inline float trace_shadow_t(const DevScene &S, V3 o, V3 d, float t_ma
         const int type = S.nodes[n].obj_type;
         if (type == BHRT_OBJ_NONE) continue;
         if (kMode == 2 && type != BHRT_OBJ_MESH) continue;
+        if (kMode == 3 && type == BHRT_OBJ_MESH) continue; // cannot happen
         const int depth = S.nodes[n].depth;
         const int32_t *ch = S.chain + (size_t)n * BHRT_MAX_NODE_DEPTH;
         V3 pp = rp, pd = rd; // ray in the PARENT's space (used by the plane test, Q1)
@@ -732,6 +738,7 @@ __device__ inline float trace_shadow_t(const DevScene &S, V3 o, V3 d, float t_ma
                 if (!(x.x < -1 || x.x > 1 || x.y < -1 || x.y > 1))
                     if (t < t_max && t > BHRT_SHADOW_BIAS) return 0.f;
             }
+        } else if (kMode == 3) {
         } else if (kMode == 1) {
             float tm; // the root box gate of TriObj::ShadowRecursive (TriObj.cpp:41-54), repeated by mesh_shadow
             if (!wants_mesh && box_hit_rcp<false>(node_at(mesh_ref(S, S.nodes[n].mesh), 1).b, lp, ld, ray_rcp(ld), BHRT_BIGFLOAT, tm)) wants_mesh = true;

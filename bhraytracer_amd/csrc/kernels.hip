@@ -254,10 +254,10 @@ __device__ inline uint32_t shading_class(uint32_t meta, const Hit &hit)
 // Closest hit of every queued ray.  meta == nullptr: every ray uses `uniform_side` (public bhrt_trace_closest_*).
 // kPark (scenes with meshes, render path): rays that reach a mesh whose root box they hit are parked on list RC_MESH
 // with their state in the hit buffer (front = front | (node + 1) << 8) and finished by k_trace_mesh.
-template <bool kPark, bool kCamera>
+template <bool kPark, bool kCamera, bool kMeshes = true>
 __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, PassInfo P, RayQueue q, uint32_t n, int uniform_side, HitBuf h, RayOrder ord, Counters *cnt)
 {
-    __shared__ bhrt_bvh_node nodelet[kPark ? 1 : BHRT_LDS_NODES]; // top BVH levels of the mesh being traversed (device_trace.h)
+    __shared__ bhrt_bvh_node nodelet[(kPark || !kMeshes) ? 1 : BHRT_LDS_NODES]; // top BVH levels of the mesh being traversed (device_trace.h)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool active = i < n;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, PassInfo P
     const bool dead = has_meta && (meta & 15u) == RK_DEAD;
     Hit hit;
     uint32_t key = 0;
-    const int parked = trace_closest(S, o, d, side, hit, active && !dead, kPark ? nullptr : nodelet, 0, kPark, kPark ? &key : nullptr); // uniform call: the block stages nodelets together
+    const int parked = trace_closest<kMeshes>(S, o, d, side, hit, active && !dead, (kPark || !kMeshes) ? nullptr : nodelet, 0, kPark, kPark ? &key : nullptr); // uniform call: the block stages nodelets together
     if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front | ((parked + 1) << 8); }
     if (kPark && parked >= 0) ord.park_key[i] = key;
     if (!ord.idx) return; // public trace API: no shading order wanted (uniform)
@@ -377,13 +377,14 @@ __global__ void __launch_bounds__(kBlock) k_file_parked(RayQueue q, HitBuf h, Ra
 // frame == nullptr: visibility goes to vis[i] (public bhrt_trace_shadow_*), else to vis[frame[i]]
 // n_dev != nullptr: the queue length is read on the device (launched ahead of the host's copy of the counters with a
 // grid sized for the upper bound n)
+template <bool kMeshes> // false: scene without meshes (trace_shadow_t<3>)
 __global__ void __launch_bounds__(kBlock) k_trace_shadow(DevScene S, ShadowQueue q, uint32_t n, const uint32_t *n_dev, float *vis)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (n_dev) n = min(n, *n_dev);
     if (i >= n) return;
     const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]), d = v3(q.dx[i], q.dy[i], q.dz[i]);
-    const float v = trace_shadow(S, o, d, q.tmax[i]);
+    const float v = kMeshes ? trace_shadow_t<0>(S, o, d, q.tmax[i]) : trace_shadow_t<3>(S, o, d, q.tmax[i]);
     vis[q.frame ? q.frame[i] : i] = v;
 }
 // Scenes with meshes, render path: spheres and planes here; a ray they leave unoccluded that enters a mesh's root box
@@ -1667,8 +1668,8 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                     auto mesh_kernel = first_step ? (path_ok ? k_trace_mesh<true, true> : k_trace_mesh<true, false>) : (path_ok ? k_trace_mesh<false, true> : k_trace_mesh<false, false>);
                     hipLaunchKernelGGL(mesh_kernel, first_step ? dim3(tg.x + BHRT_ORDER_SHARDS) /* shard segments padded to whole slices */ : tg, tb, 0, D->stream, D->S, P, Q[cur], HB, RO, D->d_cnt);
                     if (!first_step) hipLaunchKernelGGL(k_file_parked, dim3(tg.x + BHRT_ORDER_SHARDS), tb, 0, D->stream, Q[cur], HB, RO, D->d_cnt);
-                } else if (first_step) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, true>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
+                } else if (first_step) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, true, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, false, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
                 t.Stop();
             }
             st->launches_trace_closest++;
@@ -1692,7 +1693,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                     hipLaunchKernelGGL(k_trace_shadow_park, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis, RO, D->d_cnt);
                     hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
                     hipLaunchKernelGGL(path_ok ? k_shadow_mesh<true> : k_shadow_mesh<false>, dim3(hg.x + BHRT_ORDER_SHARDS), hb, 0, D->stream, D->S, SQ, F.vis, RO);
-                } else hipLaunchKernelGGL(k_trace_shadow, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis);
+                } else hipLaunchKernelGGL(k_trace_shadow<false>, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis);
                 t.Stop();
             }
             rc = WaitPublished(D, seq);
@@ -1862,7 +1863,9 @@ int bhrt_trace_closest_dev(bhrt_scene *scene, const float *d_rays_soa, int hit_s
     HitBuf h; h.t = d_out.t; h.node = d_out.node; h.prim = d_out.prim; h.front = d_out.front;
     hipStream_t s = stream ? (hipStream_t)stream : scene->dev->stream;
     RayOrder no_order = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, false>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, PassInfo(), q, (uint32_t)n, hit_side, h, no_order, (Counters *)nullptr);
+    auto closest_kernel = scene->flat.hdr()->n_meshes > 0 ? k_trace_closest<false, false, true> : k_trace_closest<false, false, false>;
+    hipLaunchKernelGGL(closest_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       scene->dev->S, PassInfo(), q, (uint32_t)n, hit_side, h, no_order, (Counters *)nullptr);
     HIP_CHECK(hipGetLastError());
     if (!stream) HIP_CHECK(hipStreamSynchronize(s));
     return BHRT_OK;
@@ -1900,7 +1903,9 @@ int bhrt_trace_shadow_dev(bhrt_scene *scene, const float *d_rays_soa, const floa
     q.ox = f; q.oy = f + n; q.oz = f + 2 * n; q.dx = f + 3 * n; q.dy = f + 4 * n; q.dz = f + 5 * n;
     q.tmax = const_cast<float *>(d_tmax); q.frame = nullptr;
     hipStream_t s = stream ? (hipStream_t)stream : scene->dev->stream;
-    hipLaunchKernelGGL(k_trace_shadow, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, q, (uint32_t)n, (const uint32_t *)nullptr, d_vis);
+    auto shadow_kernel = scene->flat.hdr()->n_meshes > 0 ? k_trace_shadow<true> : k_trace_shadow<false>;
+    hipLaunchKernelGGL(shadow_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, scene->dev->S, q,
+                       (uint32_t)n, (const uint32_t *)nullptr, d_vis);
     HIP_CHECK(hipGetLastError());
     if (!stream) HIP_CHECK(hipStreamSynchronize(s));
     return BHRT_OK;
