@@ -1709,13 +1709,6 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             } else pass_closest += n_cur;
             const uint32_t n_sh = hc.n_shadow;
             if (n_sh) { st->shadow_rays += n_sh; st->launches_trace_shadow++; }
-            if (o.photon_map && hc.n_frames > frame_marks.back()) { // caustic term of the frames opened in this step
-                Timer t(D, &st->reserved[0], 0);
-                const GatherToFrames sink = {F, D->S.materials};
-                rc = RunGather(D, sink, frame_marks.back(), hc.n_frames - frame_marks.back(), 0.5f /* MAX_Area, MtlBlinn.cpp:29 */, st);
-                if (rc) return rc;
-                t.Stop();
-            }
             frame_marks.push_back(hc.n_frames);
             n_cur = hc.n_next;
             cur ^= 1;
@@ -1727,6 +1720,16 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             if (pass_limit <= (uint32_t)o.spp) { SetError("wavefront buffers overflow even with one pixel per pass"); return BHRT_ERR_OVERFLOW; }
             pass_limit = std::max<uint32_t>((uint32_t)o.spp, pass_limit / 2);
             continue;
+        }
+        if (o.photon_map && frame_marks.back() > 0) {
+            // caustic term (MtlBlinn.cpp:329-342) of every frame of the pass in ONE gather: a gather launch lasts as long as its
+            // longest query (15-80 ms for a query that fills the 1000-candidate heap), so a gather per wave step — 23 steps
+            // per pass, most with a few hundred frames — spent 2 s per frame waiting for single lanes
+            Timer t(D, &st->reserved[0], 0);
+            const GatherToFrames sink = {F, D->S.materials};
+            int rc = RunGather(D, sink, 0, frame_marks.back(), 0.5f /* MAX_Area, MtlBlinn.cpp:29 */, st);
+            if (rc) return rc;
+            t.Stop();
         }
         st->shade_calls += D->h_pub->n_frames;
         st->closest_rays += pass_closest;
