@@ -1102,12 +1102,24 @@ __device__ inline uint32_t gather_cell(const GatherGrid &G, V3 p)
                 fz = fminf(fmaxf((p.z - G.lo[2]) * G.inv_cell[2], 0.f), m); // NaN -> 0 (fmaxf returns the number)
     return spread3((uint32_t)fx) | (spread3((uint32_t)fy) << 1) | (spread3((uint32_t)fz) << 2);
 }
+// Queries that cannot meet a photon — farther than the radius from the photons' bounds (most pixels of a caustic scene), or
+// frames without the term — are answered here and left out of the order: pass 1 then runs over the rest only.
+#define BHRT_GATHER_NO_CELL 0xffffffffu
 template <class Sink>
-__global__ void __launch_bounds__(kBlock) k_gather_cell_count(Sink sink, uint32_t q0, uint32_t cnt, GatherGrid G, uint32_t *cell_of, uint32_t *cell_count)
+__global__ void __launch_bounds__(kBlock) k_gather_cell_count(Sink sink, uint32_t q0, uint32_t cnt, GatherGrid G, PhotonMapDev M, float radius, uint32_t *cell_of,
+                                                              uint32_t *cell_count)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cnt) return;
-    const uint32_t c = gather_cell(G, sink.pos(q0 + i));
+    const uint32_t q = q0 + i;
+    if (sink.skip(q)) { cell_of[i] = BHRT_GATHER_NO_CELL; return; }
+    const V3 p = sink.pos(q);
+    if (photon_outside_bounds(M, p, radius)) { // photon_estimate_fast's own first test: no photon, zero estimate
+        cell_of[i] = BHRT_GATHER_NO_CELL;
+        sink.done(q, false, v3(0, 0, 0), v3(0, 0, 0));
+        return;
+    }
+    const uint32_t c = gather_cell(G, p);
     cell_of[i] = c;
     atomicAdd(&cell_count[c], 1u);
 }
@@ -1156,7 +1168,8 @@ __global__ void __launch_bounds__(kBlock) k_gather_cell_scatter(uint32_t q0, uin
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cnt) return;
-    order[atomicAdd(&cell_cursor[cell_of[i]], 1u)] = q0 + i;
+    const uint32_t c = cell_of[i];
+    if (c != BHRT_GATHER_NO_CELL) order[atomicAdd(&cell_cursor[c], 1u)] = q0 + i;
 }
 
 // Pass 1: every query walks the map without a candidate list (photon_estimate_fast).  Queries that meet their 1000th
@@ -1521,8 +1534,10 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
         HIP_CHECK(hipMalloc(&D->d_tile_sums, (size_t)kScanBlock * sizeof(uint32_t)));
     }
     static_assert(BHRT_GATHER_CELLS / kScanTile <= kScanBlock, "one block scans the tile sums");
-    const dim3 grid((cnt + kBlock - 1) / kBlock), block(kBlock);
+    dim3 grid((cnt + kBlock - 1) / kBlock);
+    const dim3 block(kBlock);
     const uint32_t *order = nullptr;
+    uint32_t n_walk = cnt; // queries of pass 1
     if (cnt >= (1u << 16)) { // small batches are latency-bound anyway
         GatherGrid G;
         for (int k = 0; k < 3; k++) {
@@ -1532,20 +1547,27 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
         }
         const uint32_t n_tiles = BHRT_GATHER_CELLS / kScanTile;
         HIP_CHECK(hipMemsetAsync(D->d_cells, 0, (size_t)BHRT_GATHER_CELLS * sizeof(uint32_t), D->stream));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_cell_count<Sink>), grid, block, 0, D->stream, sink, q0, cnt, G, D->d_cell_of, D->d_cells);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_cell_count<Sink>), grid, block, 0, D->stream, sink, q0, cnt, G, D->pm, radius, D->d_cell_of, D->d_cells);
         hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, D->d_cells, BHRT_GATHER_CELLS, D->d_tile_sums);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, D->stream, D->d_tile_sums, n_tiles);
         hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, D->d_cells, BHRT_GATHER_CELLS, D->d_tile_sums);
         hipLaunchKernelGGL(k_gather_cell_scatter, grid, block, 0, D->stream, q0, cnt, D->d_cell_of, D->d_cells, D->d_gorder);
         order = D->d_gorder;
+        // the last cell's cursor now stands at the end of the order = the number of queries that take part
+        HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_cells + (BHRT_GATHER_CELLS - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
+        HIP_CHECK(hipStreamSynchronize(D->stream));
+        n_walk = D->h_n_heavy[0];
+        grid = dim3((n_walk + kBlock - 1) / kBlock);
     }
     HIP_CHECK(hipMemsetAsync(D->d_n_heavy, 0, 2 * sizeof(uint32_t), D->stream));
     int lane_budget = BHRT_GATHER_LANE_BUDGET;
     if (const char *e = getenv("BHRT_GATHER_LANE_BUDGET")) lane_budget = std::max(1, atoi(e)); // test knob: a tiny budget sends every query through pass 2
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_fast<Sink>), grid, block, 0, D->stream, sink, q0, cnt, order, D->pm, radius, lane_budget, D->d_heavy,
-                       D->d_long, D->d_n_heavy);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_wave<Sink>), dim3(std::min<uint32_t>(cnt, 2048u)), dim3(64), 0, D->stream, sink, D->d_long, D->pm, radius,
-                       D->d_heavy, D->d_n_heavy);
+    if (n_walk > 0) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_fast<Sink>), grid, block, 0, D->stream, sink, q0, n_walk, order, D->pm, radius, lane_budget, D->d_heavy,
+                           D->d_long, D->d_n_heavy);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_wave<Sink>), dim3(std::min<uint32_t>(n_walk, 2048u)), dim3(64), 0, D->stream, sink, D->d_long, D->pm, radius,
+                           D->d_heavy, D->d_n_heavy);
+    }
     HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_n_heavy, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
     HIP_CHECK(hipStreamSynchronize(D->stream));
     const uint32_t n_heavy = D->h_n_heavy[0];
