@@ -30,6 +30,8 @@ WORKLOADS = {
     "c1": ("tests/scenes/c1_sphere_plane.xml", 640, 480, 1, -1),
     "c2": ("tests/scenes/c2_glass.xml", 1920, 1080, 16, 3),
     "c3": ("tests/scenes/c3_mesh.xml", 1920, 1080, 64, 3),
+    # BASELINE config 4: the mesh scene at 3840x2160, 256 spp on 8 GPUs = 32 spp per GPU (weak scaling like every workload here)
+    "c4": ("tests/scenes/c4_mesh_4k.xml", 3840, 2160, 32, 3),
     # BASELINE config 5: caustic photon map, 1 M photons, k = 1000, r = 0.5 (photon build timed separately, see "photon_build_s")
     "c5": ("tests/scenes/c5_caustics_hd.xml", 1920, 1080, 64, 3),
 }
