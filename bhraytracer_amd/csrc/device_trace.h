@@ -58,6 +58,9 @@ __device__ inline void local_ray(const DevScene &S, int n, V3 &p, V3 &d)
     for (int k = 0; k < depth; k++) to_node(S.nodes[ch[k]].xf, p, d);
 }
 
+#define BHRT_FAST_REL 1.9073486328125e-06f /* 2^-19 */
+#define BHRT_FAST_ABS 7.888609052210118e-31f /* 2^-100 */
+
 // Box::IntersectRay (Box.cpp:3-46).  The reference forms n.Dot(v) with axis vectors; the zero products only
 // affect the sign of a zero, which no comparison below can see, so the axis components are used directly.
 __device__ inline bool box_hit(const float *b, V3 o, V3 d, float t_max, float &t_min)
@@ -129,7 +132,6 @@ __device__ inline bool box_hit_rcp(const float *b, V3 o, V3 d, const RayRcp &r, 
 // the difference and of the tolerance themselves; otherwise (and for rays with a zero direction component, whose quotients
 // the reference replaces by +-BIGFLOAT) the box is evaluated exactly (box_hit_rcp).  Infinite or NaN approximations make
 // |diff| > tol false, i.e. indecisive.  3 instructions per quotient become 1.
-#define BHRT_FAST_ABS 7.888609052210118e-31f /* 2^-100 */
 struct RayRcpF {
     float rx, ry, rz;
     bool slow;
@@ -143,7 +145,6 @@ __device__ inline RayRcpF ray_rcp_f(V3 d)
     r.slow = !(fminf(fminf(ax, ay), az) >= BHRT_FAST_ABS && fmaxf(fmaxf(ax, ay), az) <= 1.2676506e30f /* 2^100 */);
     return r;
 }
-#define BHRT_FAST_REL 1.9073486328125e-06f /* 2^-19 */
 // 1 = hit, 0 = miss, -1 = too close to call.  One comparison decides both conditions: with u = min(tMax', t_max),
 // u - tMin' > tol means tMin < tMax and tMin < t_max for certain (tMax' >= u, and the error of tMax' relative to |u| is no
 // larger than relative to itself on the side that matters), u - tMin' < -tol means one of them fails for certain.
@@ -203,8 +204,17 @@ __device__ inline bool tri_hit(const bhrt_tri &tr, V3 o, V3 d, float dlen, int s
     V3 vN = ld3(tr.vN);
     float t_divisor = dot(vN, d);
     bool ok = t_divisor != 0;
-    float perp = t_divisor / (tr.vN_len * dlen);
-    ok = ok && !(perp > -BHRT_PERP && perp < BHRT_PERP);
+    // grazing test `abs(t_divisor / (|vN| * |d|)) < 0.001745` (TriObj.cpp:85-88): the quotient is only compared, so an
+    // approximate one (hardware reciprocal: within 2^-21 of the rounded quotient) decides unless it lies within 2^-19 of the
+    // threshold; a zero or subnormal denominator gives an infinite approximation = "not grazing", like the division does
+    const float den = tr.vN_len * dlen;
+    const float aperp = fabsf(t_divisor * __builtin_amdgcn_rcpf(den));
+    bool grazing = aperp < BHRT_PERP;
+    if (fabsf(aperp - BHRT_PERP) <= BHRT_PERP * BHRT_FAST_REL || aperp != aperp) {
+        const float perp = t_divisor / den;
+        grazing = perp > -BHRT_PERP && perp < BHRT_PERP;
+    }
+    ok = ok && !grazing;
     float t = (tr.vN_dot_v0 - dot(vN, o)) / t_divisor;
     ok = ok && !(t <= 0 || t > t_cur);
     bool hitFront = t_divisor < 0;
