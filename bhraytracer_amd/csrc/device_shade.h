@@ -78,11 +78,9 @@ __device__ inline void hit_attrs(const DevScene &S, V3 o, V3 d, float t, int nod
     } else { // triangle: TriObj.cpp:157-186
         const bhrt_mesh &m = S.meshes[nd.mesh];
         const bhrt_tri &tr = ((const bhrt_tri *)(S.blob + m.off_tris))[prim];
-        V3 v0 = ld3(tr.v0), v1 = ld3(tr.v1), v2 = ld3(tr.v2);
-        V3 vN = ld3(tr.vN);
         V3 vX = lp + t * ld;
         float a0, a1, a2;
-        tri_areas(v0, v1, v2, vN, vX, a0, a1, a2);
+        tri_areas(tr, vX, a0, a1, a2);
         float asum = a0 + a1 + a2;
         float bx = a0 / asum, by = a1 / asum, bz = a2 / asum;
         const float *vn = (const float *)(S.blob + m.off_vn);

@@ -177,14 +177,14 @@ __device__ inline int order_fast(float tmin1, float tmin2)
     return fabsf(d) > tol ? (d > 0 ? 1 : 0) : -1;
 }
 
-// barycentric part of IntersectTriangle (TriObj.cpp:105-168), shared with the attribute recomputation
-__device__ inline bool tri_areas(V3 v0, V3 v1, V3 v2, V3 vN, V3 vX, float &a0, float &a1, float &a2)
+// barycentric part of IntersectTriangle (TriObj.cpp:105-168), shared with the attribute recomputation; the vertices come
+// projected (bhrt_tri), only the hit point is projected here
+__device__ inline bool tri_areas(const bhrt_tri &tr, V3 vX, float &a0, float &a1, float &a2)
 {
-    float ax = fabsf(vN.x), ay = fabsf(vN.y), az = fabsf(vN.z);
-    float p0x = 0, p0y = 0, p1x = 0, p1y = 0, p2x = 0, p2y = 0, pXx = 0, pXy = 0;
-    if (ax >= ay && ax >= az) { p0x = v0.y; p0y = v0.z; p1x = v1.y; p1y = v1.z; p2x = v2.y; p2y = v2.z; pXx = vX.y; pXy = vX.z; }
-    else if (ay >= ax && ay >= az) { p0x = v0.x; p0y = v0.z; p1x = v1.x; p1y = v1.z; p2x = v2.x; p2y = v2.z; pXx = vX.x; pXy = vX.z; }
-    else if (az >= ay && az >= ax) { p0x = v0.x; p0y = v0.y; p1x = v1.x; p1y = v1.y; p2x = v2.x; p2y = v2.y; pXx = vX.x; pXy = vX.y; }
+    const uint32_t axis = tr.face_axis >> 30;
+    float pXx = axis == 0 ? vX.y : vX.x, pXy = axis == 2 ? vX.y : vX.z;
+    if (axis == 3) { pXx = 0; pXy = 0; }
+    const float p0x = tr.p0[0], p0y = tr.p0[1], p1x = tr.p1[0], p1y = tr.p1[1], p2x = tr.p2[0], p2y = tr.p2[1];
     // Vec2::Cross: (-y)*p.x + x*p.y (cyVector.h:260-262)
     float e1x = p1x - pXx, e1y = p1y - pXy, e2x = p2x - pXx, e2y = p2y - pXy, e0x = p0x - pXx, e0y = p0y - pXy;
     a0 = ((-e1y) * e2x + e1x * e2y) / 2.f;
@@ -220,10 +220,9 @@ __device__ inline bool tri_hit(const bhrt_tri &tr, V3 o, V3 d, float dlen, int s
     bool hitFront = t_divisor < 0;
     ok = ok && !(!hitFront && side == BHRT_HIT_FRONT) && !(hitFront && side == BHRT_HIT_BACK);
     if (!ok) return false;
-    V3 v0 = ld3(tr.v0), v1 = ld3(tr.v1), v2 = ld3(tr.v2);
     V3 vX = o + t * d;
     float a0, a1, a2;
-    if (!tri_areas(v0, v1, v2, vN, vX, a0, a1, a2)) return false;
+    if (!tri_areas(tr, vX, a0, a1, a2)) return false;
     t_out = t;
     front_out = hitFront ? 1 : 0;
     return true;
@@ -349,7 +348,7 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
                 const bhrt_tri &tr = M.ltris[off + i];
                 float t;
                 int fr;
-                if (tri_hit(tr, o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)tr.face; hfront = fr; r = true; }
+                if (tri_hit(tr, o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)(tr.face_axis & 0x3fffffffu); hfront = fr; r = true; }
             }
             any |= r;
             desc = false;
@@ -440,7 +439,7 @@ __device__ inline bool mesh_closest_stack(const MeshRef &M, V3 o, V3 d, int side
                 const bhrt_tri &tr = M.ltris[off + i];
                 float t;
                 int fr;
-                if (tri_hit(tr, o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)tr.face; hfront = fr; r = true; }
+                if (tri_hit(tr, o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)(tr.face_axis & 0x3fffffffu); hfront = fr; r = true; }
             }
             any |= r;
             desc = false;

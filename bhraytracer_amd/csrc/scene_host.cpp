@@ -1035,17 +1035,26 @@ int LoadSceneXml(const char *path, FlatScene &out, std::string &err, int bvh_dev
         std::vector<bhrt_tri> tris(o.nf);
         for (uint32_t f = 0; f < o.nf; f++) {
             memset(&tris[f], 0, sizeof(bhrt_tri));
-            memcpy(tris[f].v0, &m.v[m.f[f * 3] * 3], 12);
-            memcpy(tris[f].v1, &m.v[m.f[f * 3 + 1] * 3], 12);
-            memcpy(tris[f].v2, &m.v[m.f[f * 3 + 2] * 3], 12);
+            const float *pa = &m.v[m.f[f * 3] * 3], *pb = &m.v[m.f[f * 3 + 1] * 3], *pc = &m.v[m.f[f * 3 + 2] * 3];
             // TriObj.cpp:79,85,89: the same float operations the reference performs per intersection test
-            const V3 a = v3(tris[f].v0[0], tris[f].v0[1], tris[f].v0[2]), b = v3(tris[f].v1[0], tris[f].v1[1], tris[f].v1[2]),
-                     c = v3(tris[f].v2[0], tris[f].v2[1], tris[f].v2[2]);
+            const V3 a = v3(pa[0], pa[1], pa[2]), b = v3(pb[0], pb[1], pb[2]), c = v3(pc[0], pc[1], pc[2]);
             const V3 vN = cross(b - a, c - a);
             tris[f].vN[0] = vN.x; tris[f].vN[1] = vN.y; tris[f].vN[2] = vN.z;
             tris[f].vN_len = length(vN);
             tris[f].vN_dot_v0 = dot(vN, a);
-            tris[f].face = f;
+            // TriObj.cpp:105-131: projection plane from the largest |vN| component, first comparison that holds
+            const float ax = fabsf(vN.x), ay = fabsf(vN.y), az = fabsf(vN.z);
+            uint32_t axis = 3;
+            if (ax >= ay && ax >= az) axis = 0;
+            else if (ay >= ax && ay >= az) axis = 1;
+            else if (az >= ay && az >= ax) axis = 2;
+            const int iu = axis == 0 ? 1 : 0, iv = axis == 2 ? 1 : 2;
+            if (axis < 3) {
+                tris[f].p0[0] = pa[iu]; tris[f].p0[1] = pa[iv];
+                tris[f].p1[0] = pb[iu]; tris[f].p1[1] = pb[iv];
+                tris[f].p2[0] = pc[iu]; tris[f].p2[1] = pc[iv];
+            }
+            tris[f].face_axis = f | (axis << 30);
         }
         o.off_tris = W.Append(tris.data(), tris.size() * sizeof(bhrt_tri));
         std::vector<bhrt_tri> leaf_tris(o.nf);

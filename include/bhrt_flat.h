@@ -20,7 +20,7 @@
 #include <stdint.h>
 
 #define BHRT_FLAT_MAGIC 0x54524842u /* "BHRT" */
-#define BHRT_FLAT_VERSION 6u
+#define BHRT_FLAT_VERSION 7u
 #define BHRT_MAX_NODE_DEPTH 8 /* scene-graph depth below the root the kernels support */
 #define BHRT_BIGFLOAT 1.0e30f  /* Scenes/scene.h:38 */
 
@@ -59,16 +59,17 @@ typedef struct bhrt_bvh_node {
     uint32_t parent;
 } bhrt_bvh_node; /* 32 B */
 
-/* Pre-gathered triangle (device-friendly copy of v[f[i].v[0..2]]) plus the per-face constants that
- * TriObj::IntersectTriangle recomputes on every test (TriObj.cpp:79-89): vN = (v1-v0)x(v2-v0), |vN| and vN.v0 —
- * computed on the host with the same float operations, so the bits equal the reference's. 64 B */
+/* Pre-gathered triangle: what TriObj::IntersectTriangle recomputes on every test, formed once on the host with the same float
+ * operations, so the bits equal the reference's — vN = (v1-v0)x(v2-v0), |vN|, vN.v0 (TriObj.cpp:79-89) and the three vertices
+ * already projected on the coordinate plane that the test picks from |vN| (TriObj.cpp:105-131; the choice is a function of
+ * the triangle alone): axis 0 = (y, z), 1 = (x, z), 2 = (x, y), 3 = none of the three comparisons holds (NaN normal: the
+ * reference then works on zeros).  48 B */
 typedef struct bhrt_tri {
-    float v0[3], v1[3], v2[3];
+    float p0[2], p1[2], p2[2];
     float vN[3];
     float vN_len;
     float vN_dot_v0;
-    uint32_t face; /* triangle id (index into f[]) — lets the leaf-ordered copy skip the element-id indirection */
-    float pad;
+    uint32_t face_axis; /* triangle id (index into f[]) | axis << 30 */
 } bhrt_tri;
 
 typedef struct bhrt_mesh {
