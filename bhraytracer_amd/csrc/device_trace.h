@@ -476,6 +476,103 @@ __device__ inline bool mesh_closest_stack(const MeshRef &M, V3 o, V3 d, int side
     return any;
 }
 
+// mesh_closest_stack with the wave running, in every round, the ONE phase most of its lanes wait for (descend step / leaf /
+// climb step: a wave-uniform choice from three ballots) instead of the three phase loops in turn, each until its last lane
+// is through: same per-ray operation sequence, ~1.2x the lanes per instruction (C3 trace 61 -> 51 ms).
+__device__ inline bool mesh_closest_vote(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront, uint16_t *stack, uint32_t stride)
+{
+    float tm;
+    const NodeRec root = node_at(M, 1);
+    int st = 3; // 0 descend step, 1 leaf, 2 climb step, 3 done
+    uint32_t data = root.data;
+    if (box_hit_rcp(root.b, o, d, ray_rcp(d), ht, tm)) st = (data & 0x80000000u) ? 1 : 0;
+    const RayRcpF rf = ray_rcp_f(d);
+    const float dlen = length(d);
+    uint32_t cur = 1;
+    int depth = 0;
+    uint32_t inFar = 0, nearHit = 0, sides = 0;
+    bool r = false, any = false;
+    while (true) {
+        const int nD = __popcll(__ballot(st == 0)), nL = __popcll(__ballot(st == 1)), nC = __popcll(__ballot(st == 2));
+        if (nD + nL + nC == 0) break;
+        if (nD >= nL && nD >= nC) {
+            if (st == 0) {
+                const uint32_t c1 = data & 0x7fffffffu;
+                float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
+                NodeRec n1, n2;
+                node_pair_at(M, c1, n1, n2);
+                const uint32_t d1 = n1.data, d2 = n2.data;
+                const int f1 = rf.slow ? -1 : box_fast(n1.b, o, rf, ht, tmin1), f2 = rf.slow ? -1 : box_fast(n2.b, o, rf, ht, tmin2);
+                bool b1 = f1 == 1, b2 = f2 == 1;
+                int ord = (b1 && b2) ? order_fast(tmin1, tmin2) : (b1 ? 1 : 0);
+                if (f1 < 0 || f2 < 0 || ord < 0) {
+                    const RayRcp rr = ray_rcp(d);
+                    tmin1 = BHRT_BIGFLOAT; tmin2 = BHRT_BIGFLOAT;
+                    b1 = box_hit_rcp(n1.b, o, d, rr, ht, tmin1);
+                    b2 = box_hit_rcp(n2.b, o, d, rr, ht, tmin2);
+                    ord = tmin1 < tmin2 ? 1 : 0;
+                }
+                if (!b1 && !b2) { r = false; st = 2; }
+                else {
+                    depth++;
+                    const uint32_t bit = 1u << (depth - 1);
+                    inFar &= ~bit;
+                    nearHit &= ~bit;
+                    const bool first1 = ord == 1;
+                    cur = first1 ? c1 : c1 + 1;
+                    data = first1 ? d1 : d2;
+                    sides = first1 ? (sides & ~bit) : (sides | bit);
+                    stack[(uint32_t)depth * stride] = (uint16_t)(c1 >> 1);
+                    st = (data & 0x80000000u) ? 1 : 0;
+                }
+            }
+        } else if (nL >= nC) {
+            if (st == 1) {
+                const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
+                r = false;
+                for (uint32_t i = 0; i < count; i++) {
+                    const bhrt_tri &tr = M.ltris[off + i];
+                    float t;
+                    int fr;
+                    if (tri_hit(tr, o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)(tr.face_axis & 0x3fffffffu); hfront = fr; r = true; }
+                }
+                any |= r;
+                st = 2;
+            }
+        } else {
+            if (st == 2) {
+                const uint32_t below = depth >= 32 ? 0xffffffffu : (depth > 0 ? ((1u << depth) - 1u) : 0u);
+                const uint32_t waiting = ~inFar & below;
+                if (!waiting) { depth = 0; st = 3; }
+                else {
+                    const int l = 32 - __clz((int)waiting);
+                    const uint32_t upto = l >= 32 ? 0xffffffffu : ((1u << l) - 1u);
+                    r = r || (nearHit & below & ~upto) != 0;
+                    depth = l;
+                    const uint32_t bit = 1u << (l - 1);
+                    const uint32_t sib = ((uint32_t)stack[(uint32_t)l * stride] << 1) | (((sides >> (l - 1)) & 1u) ^ 1u);
+                    if (r) {
+                        nearHit |= bit;
+                        float tmf;
+                        const NodeRec ns = node_at(M, sib);
+                        const uint32_t ds = ns.data;
+                        int fs = rf.slow ? -1 : box_fast(ns.b, o, rf, ht, tmf);
+                        if (fs < 0) fs = box_hit_rcp(ns.b, o, d, ray_rcp(d), ht, tmf) ? 1 : 0;
+                        if (fs) { inFar |= bit; cur = sib; data = ds; st = (ds & 0x80000000u) ? 1 : 0; }
+                        else depth--; // stays in climb
+                    } else {
+                        inFar |= bit;
+                        cur = sib;
+                        data = node_data(M, sib);
+                        st = (data & 0x80000000u) ? 1 : 0;
+                    }
+                }
+            }
+        }
+    }
+    return any;
+}
+
 // TriObj::ShadowRecursive + TraceBVHShadow (TriObj.cpp:41-66,272-307): pre-order walk (child1 then child2 — the
 // evaluation order of `A | B` in the g++ build of the reference), both children visited unless NEITHER box is hit,
 // stops at the first leaf that reports a front-face hit; the range test is applied to that hit only.
@@ -701,7 +798,7 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
                 }
             }
         } else {
-            if (path ? mesh_closest_stack(M, lp, ld, side, h.t, h.prim, h.front, path, path_stride) : mesh_closest(M, lp, ld, side, h.t, h.prim, h.front)) h.node = n;
+            if (path ? mesh_closest_vote(M, lp, ld, side, h.t, h.prim, h.front, path, path_stride) : mesh_closest(M, lp, ld, side, h.t, h.prim, h.front)) h.node = n;
         }
     }
     return parked;
