@@ -626,49 +626,59 @@ __device__ inline bool mesh_shadow_stack(const MeshRef &M, V3 o, V3 d, float t_m
 {
     float tm;
     const RayRcp rr = ray_rcp(d);
-    if (!box_hit_rcp<false>(node_at(M, 1).b, o, d, rr, BHRT_BIGFLOAT, tm)) return false;
+    const NodeRec root = node_at(M, 1);
+    int st = 3; // 0 inner node, 1 leaf, 2 climb, 3 done — the wave runs the phase most of its lanes wait for (see mesh_closest_vote)
+    uint32_t data = root.data;
+    if (box_hit_rcp<false>(root.b, o, d, rr, BHRT_BIGFLOAT, tm)) st = (data & 0x80000000u) ? 1 : 0;
     const float dlen = length(d);
     const RayRcpF rf = ray_rcp_f(d);
-    uint32_t cur = 1, inSecond = 0;
+    uint32_t inSecond = 0;
     int depth = 0;
-    bool desc = true, found = false;
+    bool found = false;
     float t_min = BHRT_BIGFLOAT;
     while (true) {
-        if (desc) {
-            const uint32_t data = node_data(M, cur);
-            if (data & 0x80000000u) {
-                const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
-                float ht = BHRT_BIGFLOAT;
-                for (uint32_t i = 0; i < count; i++) {
-                    float t;
-                    int fr;
-                    if (tri_hit(M.ltris[off + i], o, d, dlen, BHRT_HIT_FRONT, ht, t, fr)) { ht = t; found = true; t_min = t; }
-                }
-                if (found) break;
-                desc = false;
-            } else {
+        const int nI = __popcll(__ballot(st == 0)), nL = __popcll(__ballot(st == 1)), nC = __popcll(__ballot(st == 2));
+        if (nI + nL + nC == 0) break;
+        if (nI >= nL && nI >= nC) {
+            if (st == 0) {
                 const uint32_t c1 = data & 0x7fffffffu;
                 float t1, t2;
                 const NodeRec n1 = node_at(M, c1), n2 = node_at(M, c1 + 1);
                 int f1 = rf.slow ? -1 : box_fast_f(n1.b, o, rf, BHRT_BIGFLOAT), f2 = rf.slow ? -1 : box_fast_f(n2.b, o, rf, BHRT_BIGFLOAT);
                 if (f1 < 0) f1 = box_hit_rcp<false>(n1.b, o, d, rr, BHRT_BIGFLOAT, t1) ? 1 : 0;
                 if (f2 < 0) f2 = box_hit_rcp<false>(n2.b, o, d, rr, BHRT_BIGFLOAT, t2) ? 1 : 0;
-                if (f1 != 1 && f2 != 1) desc = false;
+                if (f1 != 1 && f2 != 1) st = 2;
                 else {
                     depth++;
                     inSecond &= ~(1u << (depth - 1));
                     stack[(uint32_t)depth * stride] = (uint16_t)(c1 >> 1);
-                    cur = c1;
+                    data = n1.data;
+                    st = (data & 0x80000000u) ? 1 : 0;
                 }
             }
+        } else if (nL >= nC) {
+            if (st == 1) {
+                const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
+                float ht = BHRT_BIGFLOAT; // fresh HitInfo per leaf (TriObj.cpp:280)
+                for (uint32_t i = 0; i < count; i++) {
+                    float t;
+                    int fr;
+                    if (tri_hit(M.ltris[off + i], o, d, dlen, BHRT_HIT_FRONT, ht, t, fr)) { ht = t; found = true; t_min = t; }
+                }
+                st = found ? 3 : 2;
+            }
         } else {
-            const uint32_t below = depth >= 32 ? 0xffffffffu : ((1u << depth) - 1u);
-            const uint32_t waiting = ~inSecond & below;
-            if (!waiting) break;
-            depth = 32 - __clz((int)waiting);
-            inSecond |= 1u << (depth - 1);
-            cur = ((uint32_t)stack[(uint32_t)depth * stride] << 1) | 1u;
-            desc = true;
+            if (st == 2) {
+                const uint32_t below = depth >= 32 ? 0xffffffffu : (depth > 0 ? ((1u << depth) - 1u) : 0u);
+                const uint32_t waiting = ~inSecond & below;
+                if (!waiting) st = 3;
+                else {
+                    depth = 32 - __clz((int)waiting);
+                    inSecond |= 1u << (depth - 1);
+                    data = node_data(M, ((uint32_t)stack[(uint32_t)depth * stride] << 1) | 1u);
+                    st = (data & 0x80000000u) ? 1 : 0;
+                }
+            }
         }
     }
     return found && t_min > BHRT_TRI_BIAS && t_min < t_max;
