@@ -270,7 +270,10 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, PassInfo P
     uint32_t key = 0;
     const int parked = trace_closest<kMeshes>(S, o, d, side, hit, active && !dead, (kPark || !kMeshes) ? nullptr : nodelet, 0, kPark, kPark ? &key : nullptr); // uniform call: the block stages nodelets together
     if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front | ((parked + 1) << 8); }
-    if (kPark && parked >= 0) ord.park_key[i] = key;
+    if (kPark && parked >= 0) {
+        ord.park_key[i] = key;
+        if (!kCamera) atomicAdd(&ord.park_bucket[key], 1u); // histogram of the counting sort (the host cleared it); camera rays are not sorted
+    }
     if (!ord.idx) return; // public trace API: no shading order wanted (uniform)
     uint32_t cls = RC_NONE;
     if (active && !dead) cls = parked >= 0 ? (uint32_t)RC_MESH : shading_class(meta, hit);
@@ -295,16 +298,9 @@ __device__ inline bool parked_entry(const RayOrder &ord, uint32_t b, uint32_t *s
     i = active ? ord.idx[((size_t)RC_MESH * BHRT_ORDER_SHARDS + seg) * ord.shard_cap + local] : 0xffffffffu;
     return true;
 }
-// counting sort of the parked rays by coherence key: histogram, (scan: k_scan_*), scatter.  A fixed grid strides over
+// counting sort of the parked rays by coherence key: histogram (k_trace_closest, as it parks), scan (k_scan_*), scatter.  A fixed grid strides over
 // the slices: the number of parked rays is only known on the device, and a grid sized for "all rays parked" spends
 // most of a launch retiring empty workgroups.
-__global__ void __launch_bounds__(kBlock) k_park_count(RayOrder ord)
-{
-    __shared__ uint32_t s_seg;
-    uint32_t i;
-    for (uint32_t b = blockIdx.x; parked_entry(ord, b, &s_seg, i); b += gridDim.x)
-        if (i != 0xffffffffu) atomicAdd(&ord.park_bucket[ord.park_key[i]], 1u);
-}
 __global__ void __launch_bounds__(kBlock) k_park_scatter(RayOrder ord)
 {
     __shared__ uint32_t s_seg;
@@ -1674,14 +1670,15 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 Timer t(D, &st->seconds_trace_closest);
                 const dim3 tg((n_cur + kBlock - 1) / kBlock), tb(kBlock);
                 if (H->n_meshes > 0) { // park the mesh rays, then finish them in dense workgroups
+                    const uint32_t n_buckets = 1u << BHRT_PARK_KEY_BITS, n_tiles = n_buckets / kScanTile;
                     if (first_step) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<true, true>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
-                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<true, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
+                    else {
+                        HIP_CHECK(hipMemsetAsync(RO.park_bucket, 0, n_buckets * sizeof(uint32_t), D->stream)); // the trace kernel counts the keys as it parks
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<true, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
+                    }
                     hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
                     if (!first_step) { // counting sort of the parked rays by coherence key (the camera step keeps slot order)
-                        const uint32_t n_buckets = 1u << BHRT_PARK_KEY_BITS, n_tiles = n_buckets / kScanTile;
                         const dim3 pg(std::min<uint32_t>(tg.x + BHRT_ORDER_SHARDS, 4096u));
-                        HIP_CHECK(hipMemsetAsync(RO.park_bucket, 0, n_buckets * sizeof(uint32_t), D->stream));
-                        hipLaunchKernelGGL(k_park_count, pg, tb, 0, D->stream, RO);
                         hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, RO.park_bucket, n_buckets, RO.park_bucket + n_buckets);
                         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, D->stream, RO.park_bucket + n_buckets, n_tiles);
                         hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, RO.park_bucket, n_buckets, RO.park_bucket + n_buckets);
