@@ -384,99 +384,11 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
     return any;
 }
 
-// The same traversal with the path kept in LDS: stack[level * stride] holds the pair index (id >> 1) of the level's
+// The traversal with the path kept in LDS (mesh_closest_vote below): stack[level * stride] holds the pair index (id >> 1) of the level's
 // first-visited child, `side` its low id bit.  Returning from a second-visited child only passes the result up, so the climb
 // jumps straight to the deepest level still waiting in its first-visited child (a bit scan over inFar) instead of walking
 // parent links one dependent load at a time.  Needs ids < 2^17 and depth <= 32 (the caller checks the mesh).
-__device__ inline bool mesh_closest_stack(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront, uint16_t *stack, uint32_t stride)
-{
-    float tm;
-    const NodeRec root = node_at(M, 1);
-    if (!box_hit_rcp(root.b, o, d, ray_rcp(d), ht, tm)) return false;
-    const RayRcpF rf = ray_rcp_f(d);
-    const float dlen = length(d);
-    uint32_t cur = 1;
-    int depth = 0;
-    uint32_t inFar = 0, nearHit = 0, sides = 0;
-    bool desc = true, r = false, any = false;
-    uint32_t data = root.data;
-    while (true) {
-        // ---- phase 1: descend through inner nodes
-        while (desc && !(data & 0x80000000u)) {
-            const uint32_t c1 = data & 0x7fffffffu;
-            float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
-            NodeRec n1, n2;
-            node_pair_at(M, c1, n1, n2);
-            const uint32_t d1 = n1.data, d2 = n2.data;
-            const int f1 = rf.slow ? -1 : box_fast(n1.b, o, rf, ht, tmin1), f2 = rf.slow ? -1 : box_fast(n2.b, o, rf, ht, tmin2);
-            bool b1 = f1 == 1, b2 = f2 == 1;
-            int ord = (b1 && b2) ? order_fast(tmin1, tmin2) : (b1 ? 1 : 0);
-            if (f1 < 0 || f2 < 0 || ord < 0) {
-                const RayRcp rr = ray_rcp(d);
-                tmin1 = BHRT_BIGFLOAT; tmin2 = BHRT_BIGFLOAT;
-                b1 = box_hit_rcp(n1.b, o, d, rr, ht, tmin1);
-                b2 = box_hit_rcp(n2.b, o, d, rr, ht, tmin2);
-                ord = tmin1 < tmin2 ? 1 : 0;
-            }
-            if (!b1 && !b2) { r = false; desc = false; }
-            else {
-                depth++;
-                const uint32_t bit = 1u << (depth - 1);
-                inFar &= ~bit;
-                nearHit &= ~bit;
-                const bool first1 = ord == 1;
-                cur = first1 ? c1 : c1 + 1;
-                data = first1 ? d1 : d2;
-                sides = first1 ? (sides & ~bit) : (sides | bit);
-                stack[(uint32_t)depth * stride] = (uint16_t)(c1 >> 1);
-            }
-        }
-        // ---- phase 2: leaf
-        if (desc) {
-            const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
-            r = false;
-            for (uint32_t i = 0; i < count; i++) {
-                const bhrt_tri &tr = M.ltris[off + i];
-                float t;
-                int fr;
-                if (tri_hit(tr, o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)(tr.face_axis & 0x3fffffffu); hfront = fr; r = true; }
-            }
-            any |= r;
-            desc = false;
-        }
-        // ---- phase 3: up to the deepest level whose first-visited child has just returned
-        while (!desc && depth > 0) {
-            const uint32_t below = depth >= 32 ? 0xffffffffu : ((1u << depth) - 1u); // levels 1..depth
-            const uint32_t waiting = ~inFar & below;
-            if (!waiting) { depth = 0; break; } // every level is in its second child: the root call returns
-            const int l = 32 - __clz((int)waiting); // that level
-            const uint32_t upto = l >= 32 ? 0xffffffffu : ((1u << l) - 1u);
-            r = r || (nearHit & below & ~upto) != 0; // `first child's r ? true : r` of the levels passed
-            depth = l;
-            const uint32_t bit = 1u << (l - 1);
-            const uint32_t sib = ((uint32_t)stack[(uint32_t)l * stride] << 1) | (((sides >> (l - 1)) & 1u) ^ 1u);
-            if (r) {
-                nearHit |= bit;
-                float tmf;
-                const NodeRec ns = node_at(M, sib);
-                const uint32_t ds = ns.data;
-                int fs = rf.slow ? -1 : box_fast(ns.b, o, rf, ht, tmf);
-                if (fs < 0) fs = box_hit_rcp(ns.b, o, d, ray_rcp(d), ht, tmf) ? 1 : 0;
-                if (fs) { inFar |= bit; cur = sib; data = ds; desc = true; }
-                else depth--; // r stays true
-            } else {
-                inFar |= bit;
-                cur = sib;
-                data = node_data(M, sib);
-                desc = true;
-            }
-        }
-        if (!desc) break;
-    }
-    return any;
-}
-
-// mesh_closest_stack with the wave running, in every round, the ONE phase most of its lanes wait for (descend step / leaf /
+// ... and with the wave running, in every round, the ONE phase most of its lanes wait for (descend step / leaf /
 // climb step: a wave-uniform choice from three ballots) instead of the three phase loops in turn, each until its last lane
 // is through: same per-ray operation sequence, ~1.2x the lanes per instruction (C3 trace 61 -> 51 ms).
 __device__ inline bool mesh_closest_vote(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront, uint16_t *stack, uint32_t stride)
@@ -620,7 +532,7 @@ __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
     return found && t_min > BHRT_TRI_BIAS && t_min < t_max;
 }
 
-// mesh_shadow with the path in LDS (see mesh_closest_stack): after a subtree the walk continues at the second child of the
+// mesh_shadow with the path in LDS (see mesh_closest_vote): after a subtree the walk continues at the second child of the
 // deepest level still in its first child, found by a bit scan; no parent links are read.
 __device__ inline bool mesh_shadow_stack(const MeshRef &M, V3 o, V3 d, float t_max, uint16_t *stack, uint32_t stride)
 {
@@ -764,7 +676,7 @@ __device__ inline uint32_t park_spread(uint32_t v) // 5 bits -> every third bit
 }
 // kMeshes = false: the scene has no mesh node; the BVH code is not compiled in (half the registers: 8 waves per SIMD instead of
 // 5, C2 trace 1.13 -> 0.90 ms).
-// path != nullptr: this lane's column of the LDS path stack (stride path_stride, 33 rows) -> mesh_closest_stack; the caller has
+// path != nullptr: this lane's column of the LDS path stack (stride path_stride, 33 rows) -> mesh_closest_vote; the caller has
 // checked that every mesh qualifies.  lds_nodes: size of the nodelet buffer behind `lds`.
 template <bool kMeshes = true>
 __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit &h, bool active = true, bhrt_bvh_node *lds = nullptr, int start = 0,

@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(kBlock) k_park_scatter(RayOrder ord)
 // The parked rays in key order, one dense workgroup per kBlock of them: resume at the mesh node, finish the scene
 // graph, file the ray under its shading class (shard = workgroup mod 32: k_trace_closest left room for that, see
 // EnsureWorkspace).
-// kPath: the traversal keeps its path in LDS (mesh_closest_stack; every mesh has ids < 2^17 and depth <= 32 — the host checks).
+// kPath: the traversal keeps its path in LDS (mesh_closest_vote; every mesh has ids < 2^17 and depth <= 32 — the host checks).
 // Six waves per SIMD: the kernel waits on dependent node fetches with 8 of 64 lanes busy; more waves in flight are worth the
 // few spilled registers (5 -> 6 waves: -4 %; 7: no further gain), so the nodelet is 256 nodes here (8 KB + 17 KB of path).
 constexpr uint32_t kMeshNodelet = 256;
