@@ -318,7 +318,7 @@ constexpr uint32_t kMeshNodelet = 256;
 template <bool kCamera, bool kPath>
 __global__ void __launch_bounds__(kBlock, 6) k_trace_mesh(DevScene S, PassInfo P, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
 {
-    __shared__ bhrt_bvh_node nodelet[kMeshNodelet];
+    __shared__ bhrt_bvh_node nodelet[kPath ? 1 : kMeshNodelet]; // the LDS-path traversal reads its nodes from global memory
     __shared__ uint16_t path[kPath ? 33 * kBlock : 1];
     __shared__ uint32_t s_seg;
     bool active;
@@ -347,7 +347,8 @@ __global__ void __launch_bounds__(kBlock, 6) k_trace_mesh(DevScene S, PassInfo P
         hit.front = fw & 0xff;
         start = (fw >> 8) - 1;
     }
-    trace_closest(S, o, d, (int)((meta >> 4) & 3u), hit, active, nodelet, active ? start : S.n_nodes, false, nullptr, kPath ? path + threadIdx.x : nullptr, kBlock, kMeshNodelet);
+    trace_closest(S, o, d, (int)((meta >> 4) & 3u), hit, active, kPath ? nullptr : nodelet, active ? start : S.n_nodes, false, nullptr, kPath ? path + threadIdx.x : nullptr, kBlock,
+                  kMeshNodelet);
     if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; }
     // key-sorted rays are filed for shading by k_file_parked, in queue order instead of traversal order
     if (kCamera) file_ray(active ? shading_class(meta, hit) : (uint32_t)RC_NONE, i, blockIdx.x & (BHRT_ORDER_SHARDS - 1), ord, cnt);
