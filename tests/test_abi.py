@@ -84,3 +84,15 @@ def test_compute_refuses_without_a_device(load_scene, B):
         sc.trace_closest(np.zeros((4, 3), np.float32), np.ones((4, 3), np.float32))
     with pytest.raises(B.BhrtError):
         sc.render(B.default_opts(spp=1))
+    # the entry points added later: global photon map, images beside the colour image, device BVH build
+    with pytest.raises(B.BhrtError):
+        sc.photon_build_global(B.default_opts(), 100)
+    with pytest.raises(B.BhrtError):
+        sc.first_hit()
+    with pytest.raises(B.BhrtError, match="(?i)device"):
+        B.bvh_build(np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0]]), np.uint32([[0, 1, 2]]))
+    from conftest import SCENES
+    import os
+    with pytest.raises(B.BhrtError):                    # a scene with a mesh asked to build its BVH on a device that is not there
+        B.Scene(os.path.join(SCENES, "c3_mesh_small.xml"), bvh_device=0)
+    assert B.Scene(os.path.join(SCENES, "c3_mesh_small.xml")).info.n_triangles == 288   # the host front-end needs no device
