@@ -408,11 +408,12 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
 // The traversal with the path kept in LDS (mesh_closest_vote below): stack[level * stride] holds the pair index (id >> 1) of the level's
 // first-visited child, `side` its low id bit.  Returning from a second-visited child only passes the result up, so the climb
 // jumps straight to the deepest level still waiting in its first-visited child (a bit scan over inFar) instead of walking
-// parent links one dependent load at a time.  Needs ids < 2^17 and depth <= 32 (the caller checks the mesh).
+// parent links one dependent load at a time.  Needs depth <= 32 (the caller checks the meshes) and a path element wide enough for the pair indices.
 // ... and with the wave running, in every round, the ONE phase most of its lanes wait for (descend step / leaf /
 // climb step: a wave-uniform choice from three ballots) instead of the three phase loops in turn, each until its last lane
 // is through: same per-ray operation sequence, ~1.2x the lanes per instruction (C3 trace 61 -> 51 ms).
-__device__ inline bool mesh_closest_vote(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront, uint16_t *stack, uint32_t stride)
+template <class PathT> // uint16_t (pair indices < 2^16: meshes below 2^17 nodes) or uint32_t
+__device__ inline bool mesh_closest_vote(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront, PathT *stack, uint32_t stride)
 {
     float tm;
     const NodeRec root = node_at_g(M, 1);
@@ -455,7 +456,7 @@ __device__ inline bool mesh_closest_vote(const MeshRef &M, V3 o, V3 d, int side,
                     cur = first1 ? c1 : c1 + 1;
                     data = first1 ? d1 : d2;
                     sides = first1 ? (sides & ~bit) : (sides | bit);
-                    stack[(uint32_t)depth * stride] = (uint16_t)(c1 >> 1);
+                    stack[(uint32_t)depth * stride] = (PathT)(c1 >> 1);
                     st = (data & 0x80000000u) ? 1 : 0;
                 }
             }
@@ -555,7 +556,8 @@ __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
 
 // mesh_shadow with the path in LDS (see mesh_closest_vote): after a subtree the walk continues at the second child of the
 // deepest level still in its first child, found by a bit scan; no parent links are read.
-__device__ inline bool mesh_shadow_stack(const MeshRef &M, V3 o, V3 d, float t_max, uint16_t *stack, uint32_t stride)
+template <class PathT>
+__device__ inline bool mesh_shadow_stack(const MeshRef &M, V3 o, V3 d, float t_max, PathT *stack, uint32_t stride)
 {
     float tm;
     const RayRcp rr = ray_rcp(d);
@@ -584,7 +586,7 @@ __device__ inline bool mesh_shadow_stack(const MeshRef &M, V3 o, V3 d, float t_m
                 else {
                     depth++;
                     inSecond &= ~(1u << (depth - 1));
-                    stack[(uint32_t)depth * stride] = (uint16_t)(c1 >> 1);
+                    stack[(uint32_t)depth * stride] = (PathT)(c1 >> 1);
                     data = n1.data;
                     st = (data & 0x80000000u) ? 1 : 0;
                 }
@@ -699,9 +701,9 @@ __device__ inline uint32_t park_spread(uint32_t v) // 5 bits -> every third bit
 // 5, C2 trace 1.13 -> 0.90 ms).
 // path != nullptr: this lane's column of the LDS path stack (stride path_stride, 33 rows) -> mesh_closest_vote; the caller has
 // checked that every mesh qualifies.  lds_nodes: size of the nodelet buffer behind `lds`.
-template <bool kMeshes = true>
+template <bool kMeshes = true, class PathT = uint16_t>
 __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit &h, bool active = true, bhrt_bvh_node *lds = nullptr, int start = 0,
-                                    bool park = false, uint32_t *park_key = nullptr, uint16_t *path = nullptr, uint32_t path_stride = 0,
+                                    bool park = false, uint32_t *park_key = nullptr, PathT *path = nullptr, uint32_t path_stride = 0,
                                     uint32_t lds_nodes = BHRT_LDS_NODES)
 {
     if (start == 0) { h.t = BHRT_BIGFLOAT; h.node = -1; h.prim = -1; h.front = 1; }
@@ -751,8 +753,8 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
 // other, so nodes are tested in index order; each test is the reference's (including its quirks Q1-Q3).
 // kMode 3: the scene has no mesh (BVH code not compiled in).  kMode 0: everything.  kMode 1: spheres and planes only; returns 2.f instead of 1.f when the ray also hits the root
 // box of a mesh (the caller parks it for k_shadow_mesh).  kMode 2: the meshes only.
-template <int kMode>
-__device__ inline float trace_shadow_t(const DevScene &S, V3 o, V3 d, float t_max, uint16_t *path = nullptr, uint32_t path_stride = 0)
+template <int kMode, class PathT = uint16_t>
+__device__ inline float trace_shadow_t(const DevScene &S, V3 o, V3 d, float t_max, PathT *path = nullptr, uint32_t path_stride = 0)
 {
     V3 rp = o, rd = d;
     to_node_identity(rp, rd); // rootNode's own ToNodeCoords

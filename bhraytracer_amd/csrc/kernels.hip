@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -315,11 +316,12 @@ __global__ void __launch_bounds__(kBlock) k_park_scatter(RayOrder ord)
 // Six waves per SIMD: the kernel waits on dependent node fetches with 8 of 64 lanes busy; more waves in flight are worth the
 // few spilled registers (5 -> 6 waves: -4 %; 7: no further gain), so the nodelet is 256 nodes here (8 KB + 17 KB of path).
 constexpr uint32_t kMeshNodelet = 256;
-template <bool kCamera, bool kPath>
+template <bool kCamera, int kPath> // kPath: 0 parent links, 1 path in LDS with 16-bit entries, 2 with 32-bit entries
 __global__ void __launch_bounds__(kBlock, 6) k_trace_mesh(DevScene S, PassInfo P, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
 {
+    typedef typename std::conditional<kPath == 2, uint32_t, uint16_t>::type PathT;
     __shared__ bhrt_bvh_node nodelet[kPath ? 1 : kMeshNodelet]; // the LDS-path traversal reads its nodes from global memory
-    __shared__ uint16_t path[kPath ? 33 * kBlock : 1];
+    __shared__ PathT path[kPath ? 33 * kBlock : 1];
     __shared__ uint32_t s_seg;
     bool active;
     uint32_t i;
@@ -347,8 +349,8 @@ __global__ void __launch_bounds__(kBlock, 6) k_trace_mesh(DevScene S, PassInfo P
         hit.front = fw & 0xff;
         start = (fw >> 8) - 1;
     }
-    trace_closest(S, o, d, (int)((meta >> 4) & 3u), hit, active, kPath ? nullptr : nodelet, active ? start : S.n_nodes, false, nullptr, kPath ? path + threadIdx.x : nullptr, kBlock,
-                  kMeshNodelet);
+    trace_closest<true, PathT>(S, o, d, (int)((meta >> 4) & 3u), hit, active, kPath ? nullptr : nodelet, active ? start : S.n_nodes, false, nullptr,
+                               kPath ? path + threadIdx.x : (PathT *)nullptr, kBlock, kMeshNodelet);
     if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; }
     // key-sorted rays are filed for shading by k_file_parked, in queue order instead of traversal order
     if (kCamera) file_ray(active ? shading_class(meta, hit) : (uint32_t)RC_NONE, i, blockIdx.x & (BHRT_ORDER_SHARDS - 1), ord, cnt);
@@ -398,15 +400,16 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow_park(DevScene S, Shadow
     }
     file_ray(v == 2.f ? (uint32_t)RC_MESH : (uint32_t)RC_NONE, i, (i >> 10) & (BHRT_ORDER_SHARDS - 1), ord, cnt);
 }
-template <bool kPath> // kPath: traversal path in LDS (mesh_shadow_stack), same condition as k_trace_mesh
+template <int kPath> // kPath: traversal path in LDS (mesh_shadow_stack), same modes as k_trace_mesh
 __global__ void __launch_bounds__(kBlock) k_shadow_mesh(DevScene S, ShadowQueue q, float *vis, RayOrder ord)
 {
+    typedef typename std::conditional<kPath == 2, uint32_t, uint16_t>::type PathT;
     __shared__ uint32_t s_seg;
-    __shared__ uint16_t path[kPath ? 33 * kBlock : 1];
+    __shared__ PathT path[kPath ? 33 * kBlock : 1];
     uint32_t i;
     if (!parked_entry(ord, blockIdx.x, &s_seg, i)) return;
     if (i == 0xffffffffu) return;
-    vis[q.frame[i]] = trace_shadow_t<2>(S, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), q.tmax[i], kPath ? path + threadIdx.x : nullptr, kBlock);
+    vis[q.frame[i]] = trace_shadow_t<2, PathT>(S, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), q.tmax[i], kPath ? path + threadIdx.x : (PathT *)nullptr, kBlock);
 }
 
 // segment table of the parked mesh rays for k_trace_mesh: 32 shards, one lane each
@@ -1622,10 +1625,13 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
     if (pass_samples < (uint32_t)o.spp) pass_samples = (uint32_t)o.spp;
     const uint32_t frames_per_sample = 6; // Shade() frames per camera sample; an overflow halves the pass and retries
     D->timers = o.timers;
-    bool path_ok = true; // k_trace_mesh's LDS path stack: 16-bit pair indices, 32 levels
+    int path_mode = 1; // the traversal's path in LDS: 1 = 16-bit pair indices, 2 = 32-bit (a mesh with 2^17 nodes or more), 0 = no (deeper than 32 levels)
     {
         const bhrt_mesh *hm = (const bhrt_mesh *)(scene->flat.blob.data() + H->off_meshes);
-        for (uint32_t k = 0; k < H->n_meshes; k++) path_ok = path_ok && hm[k].n_bvh_nodes <= (1u << 17) && hm[k].bvh_depth <= 32;
+        for (uint32_t k = 0; k < H->n_meshes; k++) {
+            if (hm[k].n_bvh_nodes > (1u << 17) && path_mode == 1) path_mode = 2;
+            if (hm[k].bvh_depth > 32) path_mode = 0;
+        }
     }
     RenderParams R;
     R.internal_bounces = o.internal_bounces; R.gi_bounces = o.gi_bounces; R.photon = o.photon_map;
@@ -1685,7 +1691,8 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                         hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, RO.park_bucket, n_buckets, RO.park_bucket + n_buckets);
                         hipLaunchKernelGGL(k_park_scatter, pg, tb, 0, D->stream, RO);
                     }
-                    auto mesh_kernel = first_step ? (path_ok ? k_trace_mesh<true, true> : k_trace_mesh<true, false>) : (path_ok ? k_trace_mesh<false, true> : k_trace_mesh<false, false>);
+                    auto mesh_kernel = first_step ? (path_mode == 1 ? k_trace_mesh<true, 1> : path_mode == 2 ? k_trace_mesh<true, 2> : k_trace_mesh<true, 0>)
+                                                  : (path_mode == 1 ? k_trace_mesh<false, 1> : path_mode == 2 ? k_trace_mesh<false, 2> : k_trace_mesh<false, 0>);
                     hipLaunchKernelGGL(mesh_kernel, first_step ? dim3(tg.x + BHRT_ORDER_SHARDS) /* shard segments padded to whole slices */ : tg, tb, 0, D->stream, D->S, P, Q[cur], HB, RO, D->d_cnt);
                     if (!first_step) hipLaunchKernelGGL(k_file_parked, dim3(tg.x + BHRT_ORDER_SHARDS), tb, 0, D->stream, Q[cur], HB, RO, D->d_cnt);
                 } else if (first_step) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, true, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
@@ -1712,7 +1719,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 if (H->n_meshes > 0) {
                     hipLaunchKernelGGL(k_trace_shadow_park, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis, RO, D->d_cnt);
                     hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
-                    hipLaunchKernelGGL(path_ok ? k_shadow_mesh<true> : k_shadow_mesh<false>, dim3(hg.x + BHRT_ORDER_SHARDS), hb, 0, D->stream, D->S, SQ, F.vis, RO);
+                    hipLaunchKernelGGL(path_mode == 1 ? k_shadow_mesh<1> : path_mode == 2 ? k_shadow_mesh<2> : k_shadow_mesh<0>, dim3(hg.x + BHRT_ORDER_SHARDS), hb, 0, D->stream, D->S, SQ, F.vis, RO);
                 } else hipLaunchKernelGGL(k_trace_shadow<false>, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis);
                 t.Stop();
             }

@@ -166,6 +166,34 @@ def test_deep_bvh_takes_the_parent_link_traversal(gpu, B, O, tmp_path):
     assert dev.flat_bytes() == blob
 
 
+def test_mesh_with_more_than_2_17_bvh_nodes(gpu, B, O, tmp_path):
+    """The LDS path of the BVH traversal holds 16-bit pair indices below 2^17 nodes and 32-bit ones above: a 320 k-triangle
+    mesh (213 k nodes) takes the 32-bit kernels.  Primary hits of every pixel and GI radiance of a region against the oracle;
+    the device BVH build against the host's on the same mesh."""
+    import shutil, sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_mesh
+    mesh = os.path.join(SCENES, "gen", "mesh_400.obj")
+    if not os.path.exists(mesh):
+        gen_mesh.generate(mesh, 400)
+    os.makedirs(tmp_path / "gen", exist_ok=True)
+    shutil.copy(mesh, tmp_path / "gen" / "mesh_400.obj")
+    xml = tmp_path / "big.xml"
+    xml.write_text(open(os.path.join(SCENES, "c3_mesh.xml")).read().replace("gen/mesh_224.obj", "gen/mesh_400.obj")
+                   .replace('<width value="1920"/>', '<width value="480"/>').replace('<height value="1080"/>', '<height value="270"/>'))
+    sc = B.Scene(str(xml))
+    assert sc.info.n_triangles == 320000 and sc.info.n_bvh_nodes > (1 << 17) and sc.info.max_bvh_depth <= 32
+    blob = sc.flat_bytes()
+    o, d = O.primary_rays(sc.flat_view())
+    h, r = sc.trace_closest(o, d, 1), O.trace_closest(blob, o, d, 1)
+    assert np.array_equal(h["node"], r["node"]) and np.array_equal(h["prim"], r["prim"]) and same_bits(h["t"], r["t"])
+    region = (180, 90, 300, 170)
+    gs, _ = sc.render_samples(B.default_opts(spp=2, seed=3), *region)
+    ro = O.render(blob, sc.width, sc.height, 2, seed=3, region=region)
+    assert same_bits(gs, ro["samples"])
+    assert B.Scene(str(xml), bvh_device=0).flat_bytes() == blob
+
+
 def test_nested_scene_graph_depth3(gpu, B, O, tmp_path):
     # recursive() back-transforms only through the hit node and its direct parent (Main.cpp:407-412, SURVEY.md Q6):
     # a depth-3 node leaves p/N in its grandparent's space; t and node index are what the tracer returns
