@@ -321,86 +321,92 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
 {
     float tm;
     const NodeRec root = node_at(M, 1);
-    if (!box_hit_rcp(root.b, o, d, ray_rcp(d), ht, tm)) return false;
+    int st = 3; // phase the lane waits for: 0 step down through an inner node, 1 leaf, 2 step up, 3 done
+    uint32_t data = root.data;
+    if (box_hit_rcp(root.b, o, d, ray_rcp(d), ht, tm)) st = (data & 0x80000000u) ? 1 : 0;
     const RayRcpF rf = ray_rcp_f(d);
     const float dlen = length(d);
     uint32_t cur = 1;
     int depth = 0;
     uint64_t inFar = 0, nearHit = 0;
-    bool desc = true, r = false, any = false;
-    uint32_t data = root.data;
-    // "while-while" form of the state machine: the lanes of a wave run the three phases together (descend through
-    // inner nodes / test a leaf / climb), so a wave executes max-per-phase work instead of the union of all
-    // three bodies on every step.
+    bool r = false, any = false;
+    // Every round the wave runs ONE phase body, the one most of its lanes wait for (see mesh_closest_vote, which also keeps
+    // the path in LDS; this form walks parent links and has no depth limit below the 64 trail bits).
     while (true) {
-        // ---- phase 1: descend through inner nodes
-        while (desc && !(data & 0x80000000u)) {
-            const uint32_t c1 = data & 0x7fffffffu;
-            float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
-            NodeRec n1, n2;
-            node_pair_at(M, c1, n1, n2);
-            const uint32_t d1 = n1.data, d2 = n2.data;
-            const int f1 = rf.slow ? -1 : box_fast(n1.b, o, rf, ht, tmin1), f2 = rf.slow ? -1 : box_fast(n2.b, o, rf, ht, tmin2);
-            bool b1 = f1 == 1, b2 = f2 == 1;
-            int ord = (b1 && b2) ? order_fast(tmin1, tmin2) : (b1 ? 1 : 0);
-            if (f1 < 0 || f2 < 0 || ord < 0) { // a comparison too close to call (or a zero direction component): the exact test
-                const RayRcp rr = ray_rcp(d);
-                tmin1 = BHRT_BIGFLOAT; tmin2 = BHRT_BIGFLOAT;
-                b1 = box_hit_rcp(n1.b, o, d, rr, ht, tmin1);
-                b2 = box_hit_rcp(n2.b, o, d, rr, ht, tmin2);
-                ord = tmin1 < tmin2 ? 1 : 0;
-            }
-            if (!b1 && !b2) { r = false; desc = false; }
-            else {
-                depth++;
-                const uint64_t bit = 1ull << (depth - 1);
-                inFar &= ~bit;
-                nearHit &= ~bit;
-                const bool first1 = ord == 1;
-                cur = first1 ? c1 : c1 + 1;
-                data = first1 ? d1 : d2;
-            }
-        }
-        // ---- phase 2: leaf
-        if (desc) {
-            const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
-            r = false;
-            for (uint32_t i = 0; i < count; i++) {
-                const bhrt_tri &tr = M.ltris[off + i];
-                float t;
-                int fr;
-                if (tri_hit(tr, o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)(tr.face_axis & 0x3fffffffu); hfront = fr; r = true; }
-            }
-            any |= r;
-            desc = false;
-        }
-        // ---- phase 3: climb until a sibling has to be visited or the root returns
-        while (!desc && depth > 0) {
-            const uint64_t bit = 1ull << (depth - 1);
-            const uint32_t sib = cur ^ 1u;
-            if (!(inFar & bit)) {
-                if (r) {
-                    nearHit |= bit;
-                    float tmf;
-                    const NodeRec ns = node_at(M, sib);
-                    const uint32_t ds = ns.data;
-                    int fs = rf.slow ? -1 : box_fast(ns.b, o, rf, ht, tmf);
-                    if (fs < 0) fs = box_hit_rcp(ns.b, o, d, ray_rcp(d), ht, tmf) ? 1 : 0;
-                    if (fs) { inFar |= bit; cur = sib; data = ds; desc = true; }
-                    else { cur = node_parent(M, cur); depth--; /* r stays true */ }
-                } else {
-                    inFar |= bit;
-                    cur = sib;
-                    data = node_data(M, sib);
-                    desc = true;
+        const int nD = __popcll(__ballot(st == 0)), nL = __popcll(__ballot(st == 1)), nC = __popcll(__ballot(st == 2));
+        if (nD + nL + nC == 0) break;
+        if (nD >= nL && nD >= nC) {
+            if (st == 0) {
+                const uint32_t c1 = data & 0x7fffffffu;
+                float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
+                NodeRec n1, n2;
+                node_pair_at(M, c1, n1, n2);
+                const uint32_t d1 = n1.data, d2 = n2.data;
+                const int f1 = rf.slow ? -1 : box_fast(n1.b, o, rf, ht, tmin1), f2 = rf.slow ? -1 : box_fast(n2.b, o, rf, ht, tmin2);
+                bool b1 = f1 == 1, b2 = f2 == 1;
+                int ord = (b1 && b2) ? order_fast(tmin1, tmin2) : (b1 ? 1 : 0);
+                if (f1 < 0 || f2 < 0 || ord < 0) { // a comparison too close to call (or a zero direction component): the exact test
+                    const RayRcp rr = ray_rcp(d);
+                    tmin1 = BHRT_BIGFLOAT; tmin2 = BHRT_BIGFLOAT;
+                    b1 = box_hit_rcp(n1.b, o, d, rr, ht, tmin1);
+                    b2 = box_hit_rcp(n2.b, o, d, rr, ht, tmin2);
+                    ord = tmin1 < tmin2 ? 1 : 0;
                 }
-            } else {
-                r = (nearHit & bit) ? true : r;
-                cur = node_parent(M, cur);
-                depth--;
+                if (!b1 && !b2) { r = false; st = 2; }
+                else {
+                    depth++;
+                    const uint64_t bit = 1ull << (depth - 1);
+                    inFar &= ~bit;
+                    nearHit &= ~bit;
+                    const bool first1 = ord == 1;
+                    cur = first1 ? c1 : c1 + 1;
+                    data = first1 ? d1 : d2;
+                    st = (data & 0x80000000u) ? 1 : 0;
+                }
+            }
+        } else if (nL >= nC) {
+            if (st == 1) {
+                const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
+                r = false;
+                for (uint32_t i = 0; i < count; i++) {
+                    const bhrt_tri &tr = M.ltris[off + i];
+                    float t;
+                    int fr;
+                    if (tri_hit(tr, o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)(tr.face_axis & 0x3fffffffu); hfront = fr; r = true; }
+                }
+                any |= r;
+                st = 2;
+            }
+        } else {
+            if (st == 2) { // one level up
+                if (depth == 0) st = 3; // the root call returned
+                else {
+                    const uint64_t bit = 1ull << (depth - 1);
+                    const uint32_t sib = cur ^ 1u;
+                    if (!(inFar & bit)) {
+                        if (r) {
+                            nearHit |= bit;
+                            float tmf;
+                            const NodeRec ns = node_at(M, sib);
+                            const uint32_t ds = ns.data;
+                            int fs = rf.slow ? -1 : box_fast(ns.b, o, rf, ht, tmf);
+                            if (fs < 0) fs = box_hit_rcp(ns.b, o, d, ray_rcp(d), ht, tmf) ? 1 : 0;
+                            if (fs) { inFar |= bit; cur = sib; data = ds; st = (ds & 0x80000000u) ? 1 : 0; }
+                            else { cur = node_parent(M, cur); depth--; /* r stays true */ }
+                        } else {
+                            inFar |= bit;
+                            cur = sib;
+                            data = node_data(M, sib);
+                            st = (data & 0x80000000u) ? 1 : 0;
+                        }
+                    } else {
+                        r = (nearHit & bit) ? true : r;
+                        cur = node_parent(M, cur);
+                        depth--;
+                    }
+                }
             }
         }
-        if (!desc) break; // depth == 0: the root call returned
     }
     return any;
 }
