@@ -695,13 +695,11 @@ __device__ inline void stage_nodelet(const DevScene &S, int mesh, bhrt_bvh_node 
 // start > 0: resume at scene node `start` with the hit so far in h (k_trace_mesh).  park = true: stop at the first mesh
 // whose root box the ray hits and return that node's index (the caller parks the ray there); -1 = ran to the end.
 // park_key (park only): coherence key of the parked ray = Morton cell of its entry point into the mesh's box + direction octant.
-__device__ inline uint32_t park_spread(uint32_t v) // 5 bits -> every third bit
+__device__ inline uint32_t park_spread(uint32_t v) // low bits -> every third bit
 {
-    v &= 0x1fu;
-    v = (v | (v << 8)) & 0x0000100fu;
-    v = (v | (v << 4)) & 0x000010c3u;
-    v = (v | (v << 2)) & 0x00001249u;
-    return v;
+    uint32_t r = 0;
+    for (int k = 0; k < BHRT_PARK_CELL_BITS; k++) r |= ((v >> k) & 1u) << (3 * k);
+    return r;
 }
 // kMeshes = false: the scene has no mesh node; the BVH code is not compiled in (half the registers: 8 waves per SIMD instead of
 // 5, C2 trace 1.13 -> 0.90 ms).
@@ -740,12 +738,12 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
                 parked = n;
                 if (park_key) { // ordering hint only: any value is correct
                     const V3 e = tm > 0 ? lp + tm * ld : lp;
-                    const float m = 31.f;
-                    const float cx = fminf(fmaxf((e.x - root.b[0]) / (root.b[3] - root.b[0]) * 32.f, 0.f), m);
-                    const float cy = fminf(fmaxf((e.y - root.b[1]) / (root.b[4] - root.b[1]) * 32.f, 0.f), m);
-                    const float cz = fminf(fmaxf((e.z - root.b[2]) / (root.b[5] - root.b[2]) * 32.f, 0.f), m);
+                    const float nn = (float)(1 << BHRT_PARK_CELL_BITS), m = nn - 1.f;
+                    const float cx = fminf(fmaxf((e.x - root.b[0]) / (root.b[3] - root.b[0]) * nn, 0.f), m);
+                    const float cy = fminf(fmaxf((e.y - root.b[1]) / (root.b[4] - root.b[1]) * nn, 0.f), m);
+                    const float cz = fminf(fmaxf((e.z - root.b[2]) / (root.b[5] - root.b[2]) * nn, 0.f), m);
                     const uint32_t oct = (ld.x < 0 ? 1u : 0u) | (ld.y < 0 ? 2u : 0u) | (ld.z < 0 ? 4u : 0u);
-                    *park_key = (oct << 15) | park_spread((uint32_t)cx) | (park_spread((uint32_t)cy) << 1) | (park_spread((uint32_t)cz) << 2);
+                    *park_key = (oct << (3 * BHRT_PARK_CELL_BITS)) | park_spread((uint32_t)cx) | (park_spread((uint32_t)cy) << 1) | (park_spread((uint32_t)cz) << 2);
                 }
             }
         } else {
