@@ -1084,15 +1084,16 @@ struct GatherToArrays { // bhrt_photon_gather_host
 // (coalesced loads, no divergence), so the queries are counting-sorted by grid cell first: 128^3 cells over the photons'
 // bounds (+ radius), cells numbered along a Morton curve so that neighbouring waves share cache lines too.  The order
 // inside a cell is whatever the atomics give: every query's result is independent of the order.
-#define BHRT_GATHER_CELL_BITS 7
+#define BHRT_GATHER_CELL_BITS 9
 #define BHRT_GATHER_CELLS (1u << (3 * BHRT_GATHER_CELL_BITS))
 struct GatherGrid { float lo[3], inv_cell[3]; };
-__device__ inline uint32_t spread3(uint32_t v) // 7 bits -> every third bit
+__device__ inline uint32_t spread3(uint32_t v) // up to 10 bits -> every third bit
 {
-    v &= 0x7fu;
-    v = (v | (v << 8)) & 0x0000700fu;
-    v = (v | (v << 4)) & 0x000430c3u;
-    v = (v | (v << 2)) & 0x00049249u;
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
 __device__ inline uint32_t gather_cell(const GatherGrid &G, V3 p)
@@ -1150,13 +1151,18 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_tiles(uint32_t *data, uint3
     for (uint32_t k = 0; k < kScanPerThread; k++) { if (base + k < n) data[base + k] = run; run += v[k]; }
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
 }
-__global__ void __launch_bounds__(kScanBlock) k_scan_sums(uint32_t *tile_sums, uint32_t n_tiles) // n_tiles <= kScanBlock
+__global__ void __launch_bounds__(kScanBlock) k_scan_sums(uint32_t *tile_sums, uint32_t n_tiles) // one workgroup, chunk after chunk
 {
     __shared__ uint32_t lds[kScanBlock / 64 + 1];
-    const uint32_t v = threadIdx.x < n_tiles ? tile_sums[threadIdx.x] : 0u;
-    uint32_t total;
-    const uint32_t r = block_exclusive_scan(v, lds, total);
-    if (threadIdx.x < n_tiles) tile_sums[threadIdx.x] = r;
+    uint32_t carry = 0;
+    for (uint32_t c = 0; c < n_tiles; c += kScanBlock) {
+        const uint32_t i = c + threadIdx.x;
+        const uint32_t v = i < n_tiles ? tile_sums[i] : 0u;
+        uint32_t total;
+        const uint32_t r = block_exclusive_scan(v, lds, total);
+        if (i < n_tiles) tile_sums[i] = carry + r;
+        carry += total;
+    }
 }
 __global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t *data, uint32_t n, const uint32_t *tile_sums)
 {
@@ -1531,9 +1537,8 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
         HIP_CHECK(hipMalloc(&D->d_n_heavy, 2 * sizeof(uint32_t)));
         HIP_CHECK(hipHostMalloc(&D->h_n_heavy, 2 * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc(&D->d_cells, (size_t)BHRT_GATHER_CELLS * sizeof(uint32_t)));
-        HIP_CHECK(hipMalloc(&D->d_tile_sums, (size_t)kScanBlock * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&D->d_tile_sums, (size_t)(BHRT_GATHER_CELLS / kScanTile + kScanBlock) * sizeof(uint32_t)));
     }
-    static_assert(BHRT_GATHER_CELLS / kScanTile <= kScanBlock, "one block scans the tile sums");
     dim3 grid((cnt + kBlock - 1) / kBlock);
     const dim3 block(kBlock);
     const uint32_t *order = nullptr;
