@@ -215,3 +215,24 @@ def test_gpu_photon_map_on_random_scenes(B, O, tmp_path):
         gs, _ = sc.render_samples(B.default_opts(spp=1, gi_bounces=1, seed=seed, photon_map=1), 0, 0, sc.width, sc.height)
         rs = O.render(blob, sc.width, sc.height, 1, gi=1, seed=seed, region=(0, 0, sc.width, sc.height), photon=1)["samples"]
         assert same_bits(gs, rs), seed
+
+
+@pytest.mark.gpu
+def test_gpu_photon_render_pass_size_and_partition_invariance(B, load_scene):
+    """The caustic term is gathered once per pass over all of the pass's frames: the image must not depend on how the frame
+    is cut into passes (1 / 82 / 554 passes) or into ranks (tiles of 2 and 3 logical ranks add up to the full image)."""
+    if B.device_count() < 1:
+        pytest.fail("no HIP device")
+    sc = load_scene("c5_caustics")
+    sc.upload(0)
+    sc.photon_build(B.default_opts(seed=1), 50000)
+    ref = sc.render(B.default_opts(spp=4, gi_bounces=2, seed=1, photon_map=1))
+    assert ref[2].passes == 1
+    for per_pass, n_pass in ((4000, 82), (4 * 148, 554)):
+        r = sc.render(B.default_opts(spp=4, gi_bounces=2, seed=1, photon_map=1, samples_per_pass=per_pass))
+        assert r[2].passes == n_pass and np.array_equal(r[0], ref[0]) and r[1].tobytes() == ref[1].tobytes()
+    for world in (2, 3):
+        acc = np.zeros_like(ref[1])
+        for rank in range(world):
+            acc += sc.render(B.default_opts(spp=4, gi_bounces=2, seed=1, photon_map=1, rank=rank, world_size=world, tile_size=16))[1]
+        assert acc.tobytes() == ref[1].tobytes()
