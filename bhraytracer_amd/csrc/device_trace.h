@@ -61,6 +61,20 @@ __device__ inline void local_ray(const DevScene &S, int n, V3 &p, V3 &d)
 #define BHRT_FAST_REL 1.9073486328125e-06f /* 2^-19 */
 #define BHRT_FAST_ABS 7.888609052210118e-31f /* 2^-100 */
 
+// local_ray for a camera ray: the origin's part of every level comes from DevScene::cam_chain (18 of the 42 operations)
+__device__ inline void local_ray_camera(const DevScene &S, int n, V3 &p, V3 &d)
+{
+    const int depth = S.nodes[n].depth;
+    const int32_t *ch = S.chain + (size_t)n * BHRT_MAX_NODE_DEPTH;
+    const float *cp = S.cam_chain + (size_t)n * BHRT_MAX_NODE_DEPTH * 3;
+    for (int k = 0; k < depth; k++) {
+        const bhrt_xform &t = S.nodes[ch[k]].xf;
+        const V3 np = ld3(cp + 3 * k);
+        d = mat_mul(t.itm, (p + d) - ld3(t.pos)) - np;
+        p = np;
+    }
+}
+
 // Box::IntersectRay (Box.cpp:3-46).  The reference forms n.Dot(v) with axis vectors; the zero products only
 // affect the sign of a zero, which no comparison below can see, so the axis components are used directly.
 __device__ inline bool box_hit(const float *b, V3 o, V3 d, float t_max, float &t_min)
@@ -708,7 +722,7 @@ __device__ inline uint32_t park_spread(uint32_t v) // low bits -> every third bi
 template <bool kMeshes = true, class PathT = uint16_t>
 __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit &h, bool active = true, bhrt_bvh_node *lds = nullptr, int start = 0,
                                     bool park = false, uint32_t *park_key = nullptr, PathT *path = nullptr, uint32_t path_stride = 0,
-                                    uint32_t lds_nodes = BHRT_LDS_NODES)
+                                    uint32_t lds_nodes = BHRT_LDS_NODES, bool camera = false /* o = the camera position */)
 {
     if (start == 0) { h.t = BHRT_BIGFLOAT; h.node = -1; h.prim = -1; h.front = 1; }
     int parked = -1;
@@ -723,7 +737,8 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
         }
         if (!active || n < start || parked >= 0) continue;
         V3 lp = o, ld = d;
-        local_ray(S, n, lp, ld);
+        if (camera) local_ray_camera(S, n, lp, ld);
+        else local_ray(S, n, lp, ld);
         float t;
         int fr;
         if (type == BHRT_OBJ_SPHERE) {

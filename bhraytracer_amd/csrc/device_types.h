@@ -22,6 +22,10 @@ struct DevScene {
     // (MtlBlinn.cpp:311-318)
     const float *mat_r0;     // [n_materials]
     const float *light_pick; // [n_lights]
+    // the camera position carried through every node's ancestor chain (Node::ToNodeCoords, scene.h:490-496: p' = itm*(p-pos)),
+    // formed at upload with the same float operations: every camera ray shares its origin, so the kernels of the first wave
+    // step only transform the direction.  [n_nodes][BHRT_MAX_NODE_DEPTH][3]: entry k = the position after chain level k
+    const float *cam_chain;
     int32_t n_nodes, n_lights;
     float all_light_intensity;
     bhrt_camera cam;

@@ -269,7 +269,8 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, PassInfo P
     const bool dead = has_meta && (meta & 15u) == RK_DEAD;
     Hit hit;
     uint32_t key = 0;
-    const int parked = trace_closest<kMeshes>(S, o, d, side, hit, active && !dead, (kPark || !kMeshes) ? nullptr : nodelet, 0, kPark, kPark ? &key : nullptr); // uniform call: the block stages nodelets together
+    const int parked = trace_closest<kMeshes>(S, o, d, side, hit, active && !dead, (kPark || !kMeshes) ? nullptr : nodelet, 0, kPark, kPark ? &key : nullptr,
+                                              (uint16_t *)nullptr, 0, BHRT_LDS_NODES, kCamera); // uniform call: the block stages nodelets together
     if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front | ((parked + 1) << 8); }
     if (kPark && parked >= 0) {
         ord.park_key[i] = key;
@@ -1850,7 +1851,20 @@ int bhrt_scene_upload(bhrt_scene *scene, int device)
     {
         const bhrt_material *mats = (const bhrt_material *)(scene->flat.blob.data() + H->off_materials);
         const bhrt_light *lts = (const bhrt_light *)(scene->flat.blob.data() + H->off_lights);
-        std::vector<float> aux(H->n_materials + H->n_lights + 1, 0.f);
+        const size_t n_cam = (size_t)std::max<uint32_t>(H->n_nodes, 1) * BHRT_MAX_NODE_DEPTH * 3;
+        std::vector<float> aux(H->n_materials + H->n_lights + 1 + n_cam, 0.f);
+        { // DevScene::cam_chain: the camera position through every node's chain, p' = itm * (p - pos) per level
+            float *cc = aux.data() + H->n_materials + H->n_lights + 1;
+            for (uint32_t n = 0; n < H->n_nodes; n++) {
+                V3 p = v3(H->camera.pos[0], H->camera.pos[1], H->camera.pos[2]);
+                for (int k = 0; k < nodes[n].depth; k++) {
+                    const bhrt_xform &t = nodes[chain[(size_t)n * BHRT_MAX_NODE_DEPTH + k]].xf;
+                    p = mat_mul(t.itm, p - v3(t.pos[0], t.pos[1], t.pos[2]));
+                    float *o3 = cc + ((size_t)n * BHRT_MAX_NODE_DEPTH + k) * 3;
+                    o3[0] = p.x; o3[1] = p.y; o3[2] = p.z;
+                }
+            }
+        }
         for (uint32_t m = 0; m < H->n_materials; m++) {
             const float ior = mats[m].ior;
             const double r0d = (double)((1 - ior) / (1 + ior));
@@ -1861,6 +1875,7 @@ int bhrt_scene_upload(bhrt_scene *scene, int device)
         HIP_CHECK(hipMemcpy(D->d_aux, aux.data(), aux.size() * sizeof(float), hipMemcpyHostToDevice));
         S.mat_r0 = D->d_aux;
         S.light_pick = D->d_aux + H->n_materials;
+        S.cam_chain = D->d_aux + H->n_materials + H->n_lights + 1;
     }
     S.cam = H->camera; S.background = H->background; S.environment = H->environment;
     S.tapx[0] = S.tapy[0] = 0;
