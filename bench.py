@@ -156,7 +156,10 @@ def main():
     photon_build_s = None
     if args.workload == "c5":
         t0 = time.perf_counter()
-        n_ph = sc.photon_build(opts, args.photons)  # every rank builds the same map (emission is keyed by emission index)
+        if N > 1:  # emission sharded over the ranks by emission-index range, one all_gather per batch, the same map on every rank
+            n_ph = BD.photon_build_sharded(sc, opts, args.photons, rank, N, device=None if args.rehearse_on_one_gpu else dev)
+        else:
+            n_ph = sc.photon_build(opts, args.photons)
         torch.cuda.synchronize()
         photon_build_s = time.perf_counter() - t0
         opts.photon_map = 1

@@ -67,7 +67,7 @@ EXPORTS = [
     "bhrt_photon_get", "bhrt_photon_export", "bhrt_photon_import", "bhrt_photon_build_global", "bhrt_save_png", "bhrt_math_eval_dev",
     "bhrt_tiles_block_bytes", "bhrt_tiles_pack_dev", "bhrt_tiles_unpack_dev",
     "bhrt_first_hit", "bhrt_first_hit_dev", "bhrt_zbuffer_image_dev", "bhrt_color_image_dev",
-    "bhrt_scene_load_xml_ex", "bhrt_bvh_build",
+    "bhrt_scene_load_xml_ex", "bhrt_bvh_build", "bhrt_photon_emit_range", "bhrt_photon_install",
 ]
 
 
@@ -252,6 +252,20 @@ class Scene:
         d = np.zeros_like(p)
         _check(lib().bhrt_photon_gather_host(self._h, _ptr(p), _ptr(nrm), C.c_size_t(p.shape[0]), C.c_float(radius), _ptr(irr), _ptr(d)))
         return irr, d
+
+    def photon_emit_range(self, opts: Opts, e0: int, count: int, global_map: bool = False, capacity: int = 0) -> np.ndarray:
+        """Emissions [e0, e0 + count): the photons they store, emission order, unscaled power, (n, 24) uint8 (multi-GPU build)."""
+        capacity = capacity or 16 * count
+        out = np.zeros((capacity, 24), np.uint8)
+        n = C.c_uint32(0)
+        _check(lib().bhrt_photon_emit_range(self._h, C.byref(opts), int(bool(global_map)), C.c_uint64(e0), int(count), _ptr(out), int(capacity), C.byref(n)))
+        return out[: n.value].copy()
+
+    def photon_install(self, records: np.ndarray) -> int:
+        """Emission-order records (n, 24) -> scaled, balanced and installed caustic map."""
+        r = np.ascontiguousarray(records, np.uint8).reshape(-1, 24)
+        _check(lib().bhrt_photon_install(self._h, _ptr(r), len(r)))
+        return len(r)
 
     def photon_build_global(self, opts: Opts, max_photons: int, dat_path=None) -> np.ndarray:
         """BuildPhotonMap (Main.cpp:251-295): the global photon map, balanced (n, 24) uint8 records."""

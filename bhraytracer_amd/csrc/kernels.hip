@@ -2254,6 +2254,85 @@ static int BuildPhotons(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_p
     return BHRT_OK;
 }
 
+// ---- multi-GPU photon build: emission is keyed by the emission index, so ranks emit disjoint index ranges,
+// exchange the records (one all-gather per batch, bhraytracer_amd/dist.py::photon_build_sharded) and every rank installs the
+// same map: the first max_photons records in emission order, exactly what bhrt_photon_build keeps.
+int bhrt_photon_emit_range(bhrt_scene *scene, const bhrt_opts *opts, int global_map, uint64_t e0, uint32_t count, void *photons_out, uint32_t capacity,
+                           uint32_t *n_photons)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    if (!opts || !photons_out || !n_photons || count == 0 || count % kBlock != 0 || count > (1u << 24)) { SetError("photon emit range: bad arguments (count must be a multiple of 256)"); return BHRT_ERR_ARG; }
+    DeviceState *D = scene->dev;
+    const bhrt_flat_header *H = scene->flat.hdr();
+    const bhrt_light *lights = (const bhrt_light *)(scene->flat.blob.data() + H->off_lights);
+    std::vector<int32_t> pl; // BuildCausticPhotonMap, Main.cpp:346-361 (same order as BuildPhotons)
+    for (uint32_t i = 0; i < H->n_lights; i++)
+        if (lights[i].type == BHRT_LIGHT_POINT) pl.push_back((int32_t)i);
+    if (pl.empty()) { SetError("photon map: the scene has no point light (BuildCausticPhotonMap returns false)"); return BHRT_ERR_UNSUPPORTED; }
+    auto key = [&](int32_t i) { return ((lights[i].intensity[0] + lights[i].intensity[1] + lights[i].intensity[2]) / 3.0f) * (int)lights[i].size; };
+    std::sort(pl.begin(), pl.end(), [&](int32_t a, int32_t b) { return key(a) < key(b); });
+    float sum = 0;
+    for (int32_t i : pl) sum += key(i);
+    struct Bufs {
+        DPhoton *tmp = nullptr, *out = nullptr; uint32_t *counts = nullptr, *offsets = nullptr; int32_t *pl = nullptr;
+        ~Bufs() { (void)hipFree(tmp); (void)hipFree(out); (void)hipFree(counts); (void)hipFree(offsets); (void)hipFree(pl); }
+    } b;
+    HIP_CHECK(hipMalloc(&b.counts, count * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&b.offsets, count * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&b.pl, pl.size() * sizeof(int32_t)));
+    HIP_CHECK(hipMemcpy(b.pl, pl.data(), pl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    std::vector<uint32_t> counts(count), offsets(count);
+    uint32_t cap = 8;
+    uint64_t total = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        (void)hipFree(b.tmp); b.tmp = nullptr;
+        HIP_CHECK(hipMalloc(&b.tmp, (size_t)count * cap * sizeof(DPhoton)));
+        if (global_map) hipLaunchKernelGGL(k_photon_emit<true>, dim3(count / kBlock), dim3(kBlock), 0, D->stream, D->S, opts->seed, e0, count, b.pl, (int)pl.size(), sum, b.tmp, cap, b.counts);
+        else hipLaunchKernelGGL(k_photon_emit<false>, dim3(count / kBlock), dim3(kBlock), 0, D->stream, D->S, opts->seed, e0, count, b.pl, (int)pl.size(), sum, b.tmp, cap, b.counts);
+        HIP_CHECK(hipMemcpyAsync(counts.data(), b.counts, count * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
+        HIP_CHECK(hipStreamSynchronize(D->stream));
+        uint32_t maxc = 0;
+        for (uint32_t i = 0; i < count; i++) maxc = std::max(maxc, counts[i]);
+        if (maxc <= cap) break;
+        cap = maxc; // a path stored more photons than there was room for: once more with room for all
+    }
+    for (uint32_t i = 0; i < count; i++) { offsets[i] = (uint32_t)std::min<uint64_t>(total, capacity); total += counts[i]; }
+    *n_photons = (uint32_t)std::min<uint64_t>(total, 0xffffffffull);
+    if (total > capacity) { SetError("photon emit range: photons_out too small"); return BHRT_ERR_ARG; }
+    if (total == 0) return BHRT_OK;
+    HIP_CHECK(hipMalloc(&b.out, ((size_t)total + 1) * sizeof(DPhoton)));
+    HIP_CHECK(hipMemcpyAsync(b.offsets, offsets.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, D->stream));
+    hipLaunchKernelGGL(k_photon_compact, dim3(count / kBlock), dim3(kBlock), 0, D->stream, b.tmp, cap, b.counts, b.offsets, count, (uint32_t)total, b.out);
+    HIP_CHECK(hipMemcpyAsync(photons_out, b.out + 1, (size_t)total * sizeof(DPhoton), hipMemcpyDeviceToHost, D->stream));
+    HIP_CHECK(hipStreamSynchronize(D->stream));
+    return BHRT_OK;
+}
+
+// n records in emission order with unscaled power -> ScalePhotonPowers(1 / n) (Main.cpp:380), balance, install for the gather
+int bhrt_photon_install(bhrt_scene *scene, const void *records, uint32_t n)
+{
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    if (!records || n == 0 || n > (1u << 28)) { SetError("photon install: bad arguments"); return BHRT_ERR_ARG; }
+    DeviceState *D = scene->dev;
+    DPhoton *d = nullptr;
+    HIP_CHECK(hipMalloc(&d, ((size_t)n + 1) * sizeof(DPhoton)));
+    hipError_t e = hipMemset(d, 0, sizeof(DPhoton));
+    if (e == hipSuccess) e = hipMemcpy(d + 1, records, (size_t)n * sizeof(DPhoton), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_photon_scale, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, d, n, 1.f / (float)(int)n);
+        D->h_photons.assign((size_t)n + 1, HostPhoton());
+        e = hipMemcpyAsync(D->h_photons.data(), d, ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyDeviceToHost, D->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(D->stream);
+    }
+    (void)hipFree(d);
+    HIP_CHECK(e);
+    memset(&D->h_photons[0], 0, sizeof(HostPhoton));
+    BalancePhotons(D->h_photons);
+    return InstallPhotonMap(D);
+}
+
 int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, uint32_t *n_stored)
 {
     if (!scene) { SetError("null scene"); return BHRT_ERR_ARG; }

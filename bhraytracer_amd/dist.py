@@ -85,3 +85,41 @@ def gather_framebuffer(img: torch.Tensor, tile: int, rank: int, world: int, grou
     allb = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=img.dtype, device=img.device)
     dist.all_gather_into_tensor(allb, mine, group=group)  # rank r's block lands at rows [r*per_rank, (r+1)*per_rank)
     return unpack_tiles(allb.view((world,) + tuple(mine.shape)), img.shape[1], img.shape[0], tile)
+
+
+def photon_build_sharded(scene, opts, max_photons: int, rank: int, world: int, group=None, batch: int = 1 << 20, device=None) -> int:
+    """BuildCausticPhotonMap over `world` GPUs.  Emission is keyed by the emission index: per batch of `batch`
+    emissions rank r runs the r-th slice on its GPU (bhrt_photon_emit_range), ONE all_gather moves the slices' records to
+    everybody, and every rank keeps the first max_photons records in emission order and installs the same map
+    (bhrt_photon_install) — byte for byte the map bhrt_photon_build makes on one GPU."""
+    import numpy as np
+    import torch.distributed as dist
+    per_rank = (batch // world) // 256 * 256
+    assert per_rank > 0
+    kept, total, e0 = [], 0, 0
+    budget = max_photons * 4096 + (1 << 24)  # like BuildPhotons: a scene without a caustic path ends here
+    while total < max_photons and e0 < budget:
+        mine = scene.photon_emit_range(opts, e0 + rank * per_rank, per_rank)
+        if world == 1:
+            blocks = [mine]
+        else:
+            # `device`: where the exchange buffers live — the GPU for RCCL ("nccl"), None = host memory for gloo
+            sizes = torch.zeros(world, dtype=torch.int64, device=device)
+            sizes[rank] = len(mine)
+            dist.all_reduce(sizes, group=group)
+            sizes = sizes.cpu()
+            width = max(int(sizes.max()), 1)
+            buf = torch.zeros((width, 24), dtype=torch.uint8, device=device)
+            buf[: len(mine)] = torch.from_numpy(mine).to(buf.device)
+            allb = torch.zeros((world * width, 24), dtype=torch.uint8, device=device)
+            dist.all_gather_into_tensor(allb, buf, group=group)
+            allb = allb.cpu()
+            blocks = [allb[r * width: r * width + int(sizes[r])].numpy() for r in range(world)]
+        for blk in blocks:  # rank order = emission order
+            kept.append(blk)
+            total += len(blk)
+        e0 += per_rank * world
+    if total == 0:
+        raise RuntimeError("photon map: no photon reached a photon surface")
+    rec = np.concatenate(kept)[:max_photons]
+    return scene.photon_install(rec)

@@ -137,6 +137,15 @@ int bhrt_render_samples(bhrt_scene *scene, const bhrt_opts *opts, int x0, int y0
 
 /* ---- caustic photon map (Main.cpp:342-386, DataStructure/cyPhotonMap.h) -------------------------- */
 int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, uint32_t *n_stored);
+/* Multi-GPU build of the caustic map: the emission loop of BuildCausticPhotonMap (Main.cpp:342-386) draws from
+ * a stream keyed by the emission index, so ranks can run disjoint index ranges.  bhrt_photon_emit_range runs emissions
+ * [e0, e0 + count) (count a multiple of 256) and returns the photons they store, in emission order, with unscaled power
+ * (24-byte records, host pointer; *n_photons = how many, error if more than capacity).  bhrt_photon_install takes records in
+ * emission order (after the exchange: the first MAX_CausticPhotonCount of all ranks' records), applies ScalePhotonPowers(1/n)
+ * (Main.cpp:380), balances and installs the map for bhrt_render* — the same map bhrt_photon_build makes alone. */
+int bhrt_photon_emit_range(bhrt_scene *scene, const bhrt_opts *opts, int global_map, uint64_t e0, uint32_t count, void *photons_out, uint32_t capacity,
+                           uint32_t *n_photons);
+int bhrt_photon_install(bhrt_scene *scene, const void *records_emission_order, uint32_t n);
 /* The reference's second map, BuildPhotonMap (Main.cpp:251-295; TracePhotonRay Main.cpp:296-317, RandomPhotonBounce
  * MtlBlinn.cpp:140-202): photons that survive diffuse and specular bounces.  Its only call is commented out in the reference
  * (Main.cpp:196) and nothing gathers from it, so it is built on request and handed back: balanced 24-byte records into

@@ -236,3 +236,35 @@ def test_gpu_photon_render_pass_size_and_partition_invariance(B, load_scene):
         for rank in range(world):
             acc += sc.render(B.default_opts(spp=4, gi_bounces=2, seed=1, photon_map=1, rank=rank, world_size=world, tile_size=16))[1]
         assert acc.tobytes() == ref[1].tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_photon_build_equals_single_build(B, load_scene):
+    """Multi-GPU build of the caustic map (SURVEY.md 8e; bhraytracer_amd/dist.py::photon_build_sharded): ranks emit disjoint
+    emission-index ranges, the records are concatenated in emission order, the first max_photons are installed.  Logical
+    ranks on one GPU here (the exchange itself is covered by tools/verify_multi_rank.py): the installed map equals
+    bhrt_photon_build's byte for byte, for the caustic and (records only) the global emission."""
+    if B.device_count() < 1:
+        pytest.fail("no HIP device")
+    sc = load_scene("c5_caustics")
+    opts = B.default_opts(seed=7)
+    N = 30000
+    sc.photon_build(opts, N)
+    single = sc.photon_get()
+    for world, per_rank in ((2, 1 << 16), (3, 87 * 256)):
+        kept, total, e0 = [], 0, 0
+        while total < N:
+            for rank in range(world):
+                blk = sc.photon_emit_range(opts, e0 + rank * per_rank, per_rank)
+                kept.append(blk)
+                total += len(blk)
+            e0 += per_rank * world
+        assert sc.photon_install(np.concatenate(kept)[:N]) == N
+        assert np.array_equal(sc.photon_get(), single), world
+    g = sc.photon_build_global(opts, 5000)
+    rec = np.concatenate([sc.photon_emit_range(opts, r * 4096, 4096, global_map=True) for r in range(4)])
+    assert len(rec) >= 5000 and len(g) == 5000
+    with pytest.raises(B.BhrtError):
+        sc.photon_emit_range(opts, 0, 100)          # not a multiple of 256
+    with pytest.raises(B.BhrtError):
+        sc.photon_emit_range(opts, 0, 4096, global_map=True, capacity=16)   # buffer too small

@@ -29,6 +29,15 @@ for scene, spp in (("c2_glass_small.xml", 4), ("c3_mesh_small.xml", 2)):
             same = bool((rgb.cpu().numpy() == rgb1).all()) and rad.cpu().numpy().tobytes() == rad1.tobytes()
             print(f"{scene} {W}x{H} tile {tile} world {world}: {'identical' if same else 'MISMATCH'}", flush=True)
             ok = ok and same
+# the caustic photon map built by all ranks together (emission sharded by index range, one all_gather per batch) == built alone
+sc = B.Scene(os.path.join(ROOT, "tests", "scenes", "c5_caustics.xml")); sc.upload(0)
+o = B.default_opts(seed=3)
+n = BD.photon_build_sharded(sc, o, 20000, rank, world, batch=1 << 18)
+shared = sc.photon_get()
+sc.photon_build(o, 20000)
+same = n == 20000 and bool((shared == sc.photon_get()).all())
+ok = ok and same
+print(f"rank {rank}: photon map built over {world} ranks: {'identical' if same else 'MISMATCH'}", flush=True)
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)
