@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
-"""bench.py — Mrays/s + wall-clock per frame of the HIP render path on BASELINE.json's config.
+"""bench.py — Mrays/s + wall-clock per frame of the HIP render path on BASELINE.json's configs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c3room|c4|c5|c1] [--no-configs]
 
 A "step" = one full frame of the workload through the hot path (camera rays -> wavefront
 trace/shade steps -> combine -> resolve [-> RCCL framebuffer gather when N > 1]).
-N = 1 default workload = BASELINE.json configs[1]: tests/scenes/c2_glass.xml, 1920x1080, 16 spp,
+Headline workload (N = 1 default) = BASELINE.json configs[1]: tests/scenes/c2_glass.xml, 1920x1080, 16 spp,
 GI depth 3 (4 levels = "reflection/refraction depth 4"), internal bounces 16, keyed RNG seed 0.
+The same JSON line carries, under "configs", BASELINE's heavier configurations timed the same way with a few steps each:
+c3 (100,352-triangle mesh, 64 spp), c3room (the closed Cornell room of proj13.xml around the same mesh), c4 (3840x2160,
+32 spp per GPU = 256 spp on 8) and c5 (1 M caustic photons + k-NN gather, 64 spp) — each with its own `roofline`.
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); interleaved 32x32 tiles
-(tile t -> rank t mod N), spp scaled to 16*N so per-GPU work is fixed (weak
+(tile t -> rank t mod N), spp scaled with N so per-GPU work is fixed (weak
 scaling), then one all_gather of the packed tile buffers over xGMI inside the timed region.
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself.
 The scene is resident in HBM before the timed region; outputs stay in HBM.
 
 Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` and `cpu_baseline`.
@@ -17,6 +21,8 @@ Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` and `cp
 import argparse
 import json
 import os
+import re
+import socket
 import subprocess
 import sys
 import tempfile
@@ -26,19 +32,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (scene, width, height, spp, gi)
+    # name: (scene, width, height, spp per GPU, gi)
     "c1": ("tests/scenes/c1_sphere_plane.xml", 640, 480, 1, -1),
     "c2": ("tests/scenes/c2_glass.xml", 1920, 1080, 16, 3),
     "c3": ("tests/scenes/c3_mesh.xml", 1920, 1080, 64, 3),
+    # SURVEY.md 8(d) C3, second half: the closed room of Resource/Data/proj13.xml with the same mesh in the teapot's place
+    "c3room": ("tests/scenes/c3_room.xml", 1920, 1080, 64, 3),
     # BASELINE config 4: the mesh scene at 3840x2160, 256 spp on 8 GPUs = 32 spp per GPU (weak scaling like every workload here)
     "c4": ("tests/scenes/c4_mesh_4k.xml", 3840, 2160, 32, 3),
     # BASELINE config 5: caustic photon map, 1 M photons, k = 1000, r = 0.5 (photon build timed separately, see "photon_build_s")
     "c5": ("tests/scenes/c5_caustics_hd.xml", 1920, 1080, 64, 3),
 }
-BYTES_PER_CLOSEST_RAY = 56  # 32 B ray read + 24 B hit write
-BYTES_PER_SHADOW_RAY = 36   # 32 B read + 4 B visibility write
+SIDE_CONFIGS = ["c3", "c3room", "c4", "c5"]  # reported under "configs" beside the headline
+BYTES_PER_CLOSEST_RAY = 56   # 32 B ray read + 24 B hit write
+BYTES_PER_SHADOW_RAY = 36    # 32 B read + 4 B visibility write
 BYTES_PER_SHADE_VERTEX = 92  # 24 hit + 32 ray read, 12 radiance, 24 next-ray writes
-HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_PHOTON_VISITED = 24  # 24 B x candidates scanned per query (+ 24 B out per query)
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+TILE = 32
 
 
 def ensure_assets():
@@ -50,10 +61,12 @@ def ensure_assets():
 
 
 def cpu_baseline(scene_path, spp, gi):
-    """Reference CPU path on a bounded sample of the same workload, on this box's host cores.
+    """Reference CPU path on one whole step of the same workload (the full frame), on this box's host cores.
 
     kind "reference": the reference itself (oracle/_ref/ref_harness, compiled from /root/reference in the dev
-    container) run as one single-threaded process per row band (its RNG is a process-global);
+    container) run as one single-threaded process per row band (its RNG is a process-global); the harness reports its
+    own scene-load and render times, `value` uses the slowest band's render time (= the parallel frame time), the
+    wall clock incl. process start and scene load is reported beside it;
     kind "port": the oracle (sequential RNG + libm = the mode pinned bit-for-bit to the reference), OpenMP.
     Ray counts come from the oracle (identical control flow)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -62,104 +75,77 @@ def cpu_baseline(scene_path, spp, gi):
     sc = B.Scene(scene_path)
     blob = sc.flat_bytes()
     W, H = sc.width, sc.height
-    cores = max(1, min(os.cpu_count() or 1, 16))  # the GPU box's CPU share for one GPU
-    rows = max(cores, (H // 8) // cores * cores)  # about 1/8 of the frame, a multiple of the core count
-    y0 = (H - rows) // 2
-    region = (0, y0, W, y0 + rows)
+    host_cores = os.cpu_count() or 1
+    cores = max(1, min(host_cores, 16))  # the GPU box's CPU share for one GPU is 16
+    region = (0, 0, W, H)
     t0 = time.time()
     ro = O.render(blob, W, H, spp, gi=gi, rng=O.RNG_SEQUENTIAL, math=O.MATH_LIBM, region=region, threads=cores,
                   want_samples=False)
     port_s = time.time() - t0
     rays = ro["stats"].closest_rays + ro["stats"].shadow_rays
-    sample = f"rows {y0}..{y0 + rows} of {W}x{H} ({rows * W} pixels x {spp} spp, {rays} rays)"
-    out = {"value": rays / port_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample}
+    sample = f"one whole step: {W}x{H} x {spp} spp ({W * H * spp} camera samples, {rays} rays)"
+    out = {"value": rays / port_s / 1e6, "unit": "Mrays/s", "cores": cores, "host_cores": host_cores, "kind": "port", "sample": sample,
+           "seconds": port_s}
     harness = os.path.join(ROOT, "oracle/_ref/ref_harness")
     if os.path.exists(harness):
         try:
-            band = rows // cores
             tmp = tempfile.mkdtemp(prefix="bhrt_ref_")
+            bounds = [H * k // cores for k in range(cores + 1)]
             t0 = time.time()
             procs = []
             for k in range(cores):
-                a, b = y0 + k * band, y0 + (k + 1) * band
                 cmd = [harness, os.path.abspath(scene_path), os.path.join(tmp, f"b{k}"), "--spp", str(spp), "--gi", str(gi),
-                       "--region", "0", str(a), str(W), str(b), "render"]
+                       "--region", "0", str(bounds[k]), str(W), str(bounds[k + 1]), "render"]
                 procs.append(subprocess.Popen(cmd, cwd=os.path.dirname(os.path.abspath(scene_path)),
-                                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
-            ok = all(p.wait() == 0 for p in procs)
-            ref_s = time.time() - t0
+                                              stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+            errs = [p.communicate()[1] for p in procs]
+            ok = all(p.returncode == 0 for p in procs)
+            wall_s = time.time() - t0
             if ok:
-                out = {"value": rays / ref_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference",
-                       "sample": sample + f"; {cores} single-threaded reference processes (incl. scene load)",
-                       "port_value": rays / port_s / 1e6}
+                tm = [re.search(r"load ([0-9.]+) s, commands ([0-9.]+) s", e) for e in errs]
+                render_s = max(float(m.group(2)) for m in tm) if all(tm) else wall_s
+                load_s = max(float(m.group(1)) for m in tm) if all(tm) else 0.0
+                out = {"value": rays / render_s / 1e6, "unit": "Mrays/s", "cores": cores, "host_cores": host_cores, "kind": "reference",
+                       "sample": sample + f"; {cores} single-threaded reference processes, one row band each",
+                       "seconds": render_s, "scene_load_seconds": load_s, "wall_seconds_incl_process_start": wall_s,
+                       "value_incl_process_start": rays / wall_s / 1e6, "port_value": rays / port_s / 1e6}
             subprocess.run(["rm", "-rf", tmp])
         except Exception:
             pass
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--samples-per-pass", type=int, default=0, help="camera samples in flight per wavefront pass (0 = library default)")
-    ap.add_argument("--timers", type=int, default=None, help="bhrt_opts.timers: 0 = HIP events around k_shade only (default for c2, whose dominant kernel it is), 1 = around every kernel group (default otherwise; costs ~0.2 ms of event gaps per frame), -1 = none")
-    ap.add_argument("--photons", type=int, default=1000000, help="photon budget of workload c5 (MAX_CausticPhotonCount, Main.cpp:53)")
-    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="development aid: all ranks share cuda:0 and the gather goes through gloo on host copies, "
-                         "to rehearse the N > 1 control flow on a one-GPU box (numbers are meaningless)")
-    args = ap.parse_args()
+def pmc_profile(workload):
+    """Per-launch HBM traffic (PMC, separate rocprofv3 --pmc passes) and VALU issue fraction of the workload's kernels, as
+    committed under profiles/ (tools/pmc_summary.py writes it; measured once per round, not per bench run)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(workload, {})
+    except Exception:
+        return {}
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    N = max(1, world)
 
-    import numpy as np
+def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=None):
+    """Times `steps` frames of workload `name` (barrier + synchronize on both sides, max over ranks)."""
     import torch
     import bhraytracer_amd as B
     import bhraytracer_amd.dist as BD
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    if args.rehearse_on_one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if N > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
-
-    if rank == 0:
-        ensure_assets()
-    if N > 1:
-        dist.barrier()
-    scene_rel, W, H, spp1, gi = WORKLOADS[args.workload]
+    rank, N, dev, dist, rehearse = ctx["rank"], ctx["N"], ctx["dev"], ctx["dist"], ctx["rehearse"]
+    scene_rel, W, H, spp1, gi = WORKLOADS[name]
     scene_path = os.path.join(ROOT, scene_rel)
     sc = B.Scene(scene_path)
     assert (sc.width, sc.height) == (W, H), "scene size differs from the workload table"
-    sc.upload(local_rank)
+    sc.upload(ctx["local_rank"])
     spp = spp1 * N  # weak scaling: per-GPU sample count is fixed
-    tile = 32
-    opts = B.default_opts(spp=spp, gi_bounces=gi, internal_bounces=16, seed=0, rank=rank, world_size=N, tile_size=tile)
-    opts.samples_per_pass = args.samples_per_pass
-    opts.timers = args.timers if args.timers is not None else (0 if args.workload == "c2" else 1)
+    opts = B.default_opts(spp=spp, gi_bounces=gi, internal_bounces=16, seed=0, rank=rank, world_size=N, tile_size=TILE)
+    opts.samples_per_pass = samples_per_pass
+    opts.timers = timers if timers is not None else (0 if name == "c2" else 1)
     photon_build_s = None
-    if args.workload == "c5":
+    if name == "c5":
         t0 = time.perf_counter()
         if N > 1:  # emission sharded over the ranks by emission-index range, one all_gather per batch, the same map on every rank
-            n_ph = BD.photon_build_sharded(sc, opts, args.photons, rank, N, device=None if args.rehearse_on_one_gpu else dev)
+            BD.photon_build_sharded(sc, opts, photons, rank, N, device=None if rehearse else dev)
         else:
-            n_ph = sc.photon_build(opts, args.photons)
+            sc.photon_build(opts, photons)
         torch.cuda.synchronize()
         photon_build_s = time.perf_counter() - t0
         opts.photon_map = 1
@@ -169,7 +155,6 @@ def main():
     n_buf = 2 if N > 1 else 1
     bufs = [(torch.zeros((H, W, 3), dtype=torch.uint8, device=dev), torch.zeros((H, W, 3), dtype=torch.float32, device=dev), {},
              torch.cuda.Event()) for _ in range(n_buf)]
-    d_rgb, d_rad = bufs[0][0], bufs[0][1]
     frame_no = [0]
 
     def step():
@@ -180,7 +165,7 @@ def main():
         st = sc.render_dev(opts, rgb.data_ptr(), rad.data_ptr())
         if N > 1:
             # pack -> ONE all_gather of byte blocks (RCCL; through the host with gloo when rehearsing on one GPU) -> unpack
-            BD.gather_frame_dev(rgb, rad, tile, rank, N, scratch=scratch, via_host=args.rehearse_on_one_gpu)
+            BD.gather_frame_dev(rgb, rad, TILE, rank, N, scratch=scratch, via_host=rehearse)
             ev.record()
         return st
 
@@ -190,20 +175,19 @@ def main():
         torch.cuda.synchronize()
 
     step()  # untimed: first use allocates the wavefront workspace (tens of GB of hipMalloc) — not part of any timed or warmup step
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync()
     t0 = time.perf_counter()
     agg = None
-    for _ in range(args.steps):
-        st = step()
-        d = st.as_dict()
+    for _ in range(steps):
+        d = step().as_dict()
         agg = d if agg is None else {k: agg[k] + d[k] for k in d}
     sync()
     elapsed = time.perf_counter() - t0
     rays_local = agg["closest_rays"] + agg["shadow_rays"]
     if N > 1:
-        rdev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
+        rdev = torch.device("cpu") if rehearse else dev
         tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -212,60 +196,153 @@ def main():
         rays_total, closest_total, samples_total = (float(x) for x in rr.tolist())
     else:
         rays_total, closest_total, samples_total = float(rays_local), float(agg["closest_rays"]), float(agg["camera_samples"])
+    sc.close()  # frees this workload's HBM (scene + up to ~65 GB of wavefront workspace) before the next one
+    del bufs
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+
+    # roofline of the dominant kernel group on this rank (HIP-event time measured inside the library on its stream).
+    # Algorithmic bytes per unit are SURVEY.md 8(d)'s: closest-hit ray 56 B, any-hit ray 36 B, shade vertex 92 B, photon visited 24 B.
+    gather_s = agg.get("seconds_photon_gather", 0.0)
+    k_times = {"k_trace_closest": agg["seconds_trace_closest"], "k_trace_shadow": agg["seconds_trace_shadow"],
+               "k_shade": agg["seconds_shade"], "k_photon_gather": gather_s, "other": agg["seconds_other"]}
+    units = {"k_trace_closest": (agg["closest_rays"], BYTES_PER_CLOSEST_RAY, agg["launches_trace_closest"]),
+             "k_trace_shadow": (agg["shadow_rays"], BYTES_PER_SHADOW_RAY, agg["launches_trace_shadow"]),
+             "k_shade": (agg["closest_rays"], BYTES_PER_SHADE_VERTEX, agg["launches_trace_closest"]),
+             "k_photon_gather": (agg.get("photon_nodes_visited", 0), BYTES_PER_PHOTON_VISITED, max(1, agg["passes"]))}
+    dom = max(units, key=lambda k: k_times[k])
+    n_units, bpu, launches = units[dom]
+    launches = max(1, launches)
+    avg_launch_s = k_times[dom] / launches
+    units_per_launch = n_units / launches
+    achieved = bpu * units_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    prof = pmc_profile(name)
+    per_kernel = {k: {"seconds": k_times[k], "units": units[k][0], "bytes_per_unit": units[k][1], "launches": units[k][2],
+                      "GBps": (units[k][0] * units[k][1] / k_times[k] / 1e9) if k_times[k] > 0 else 0.0} for k in units}
+    group_of = {"k_trace_closest": "k_trace_closest + k_trace_mesh + park sort (closest-hit group of one wave step)",
+                "k_trace_shadow": "k_trace_shadow(_park) + k_shadow_mesh (any-hit group of one wave step)", "k_shade": "k_shade",
+                "k_photon_gather": "k_photon_gather_* + cell sort (caustic gather of one pass)"}
+    res = {
+        "workload": f"{os.path.basename(scene_rel)} {W}x{H}, {spp} spp ({spp1} per GPU), GI depth {gi}, "
+                    f"internal bounces 16, keyed RNG seed 0, {TILE}x{TILE} interleaved tiles over {N} GPU(s)",
+        "steps": steps, "warmup": warmup,
+        "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": elapsed / steps * 1e3,
+        "rays_per_frame": rays_total / steps, "camera_samples_per_frame": samples_total / steps,
+        "rays_per_camera_sample": rays_total / max(samples_total, 1.0),
+        "wave_steps_per_frame": agg["wave_iterations"] / steps, "passes_per_frame": agg["passes"] / steps,
+        "kernel_seconds": k_times, "timers": {0: "k_shade only", 1: "every kernel group", -1: "none"}.get(opts.timers),
+        "kernels": per_kernel,
+        "roofline": {"bound": "hbm", "kernel": dom, "kernels_timed": group_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": prof.get(dom + "_bytes_per_launch"),
+                     "avg_launch_ms": avg_launch_s * 1e3, "units_per_launch": units_per_launch, "bytes_per_unit": bpu,
+                     "valu_issue_frac": prof.get(dom + "_valu_issue_frac"),
+                     "note": "scene is cache-resident; traversal/shading are latency- and VALU-issue-bound, not HBM-bound (DESIGN.md 4)"},
+    }
+    if photon_build_s is not None:
+        res["photon"] = {"build_s": photon_build_s, "gather_s_per_frame": gather_s / steps,
+                         "heavy_pass_s_per_frame": agg.get("seconds_photon_heavy", 0.0) / steps,
+                         "queries_per_frame": agg.get("photon_queries", 0) / steps,
+                         "heavy_queries_per_frame": agg.get("photon_heavy_queries", 0) / steps,
+                         "wave_queries_per_frame": agg.get("photon_wave_queries", 0) / steps,
+                         "nodes_visited_per_frame": agg.get("photon_nodes_visited", 0) / steps}
+    return res
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside a torchrun environment: start the N ranks (one per GPU) as a child
+    torch.distributed.run, before anything here touches the GPU, and leave with its exit code."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")).returncode
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="headline only: skip the 'configs' object (c3, c3room, c4, c5)")
+    ap.add_argument("--configs", default=",".join(SIDE_CONFIGS), help="workloads reported under 'configs' (default run of the headline workload c2 only)")
+    ap.add_argument("--config-steps", type=int, default=3)
+    ap.add_argument("--config-warmup", type=int, default=1)
+    ap.add_argument("--samples-per-pass", type=int, default=0, help="camera samples in flight per wavefront pass (0 = library default)")
+    ap.add_argument("--timers", type=int, default=None, help="bhrt_opts.timers: 0 = HIP events around k_shade only (default for c2, whose dominant kernel it is), 1 = around every kernel group (default otherwise; costs ~0.2 ms of event gaps per frame), -1 = none")
+    ap.add_argument("--photons", type=int, default=1000000, help="photon budget of workload c5 (MAX_CausticPhotonCount, Main.cpp:53)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development aid: all ranks share cuda:0 and the gather goes through gloo on host copies, "
+                         "to rehearse the N > 1 control flow on a one-GPU box (numbers are meaningless)")
+    args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and (world_env is None or int(world_env) != args.gpus):
+        if world_env is not None and int(world_env) != 1:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: launch with --nproc-per-node {args.gpus}")
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    N = max(1, int(world_env or "1"))
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
+    elif N > 1 and torch.cuda.device_count() < N:
+        raise SystemExit(f"bench.py: {N} ranks but only {torch.cuda.device_count()} GPU(s) visible (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if N > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
+    if rank == 0:
+        ensure_assets()
+    if N > 1:
+        dist.barrier()
+    ctx = {"rank": rank, "local_rank": local_rank, "N": N, "dev": dev, "dist": dist, "rehearse": args.rehearse_on_one_gpu}
+
+    head = run_workload(args.workload, args.steps, args.warmup, ctx, args.photons, args.samples_per_pass, args.timers)
+    configs = {}
+    if args.workload == "c2" and not args.no_configs:
+        for name in [c for c in args.configs.split(",") if c]:
+            configs[name] = run_workload(name, args.config_steps, args.config_warmup, ctx, args.photons)
 
     if rank == 0:
-        # roofline of the dominant kernel on this rank (HIP-event time measured inside the library on its stream).
-        # Algorithmic bytes per unit are SURVEY.md 8(d)'s: closest-hit ray 56 B, any-hit ray 36 B, shade vertex 92 B.
-        k_times = {"k_trace_closest": agg["seconds_trace_closest"], "k_trace_shadow": agg["seconds_trace_shadow"],
-                   "k_shade": agg["seconds_shade"], "other": agg["seconds_other"]}
-        units = {"k_trace_closest": (agg["closest_rays"], BYTES_PER_CLOSEST_RAY, agg["launches_trace_closest"]),
-                 "k_trace_shadow": (agg["shadow_rays"], BYTES_PER_SHADOW_RAY, agg["launches_trace_shadow"]),
-                 "k_shade": (agg["closest_rays"], BYTES_PER_SHADE_VERTEX, agg["launches_trace_closest"])}
-        dom = max(units, key=lambda k: k_times[k])
-        n_units, bpu, launches = units[dom]
-        launches = max(1, launches)
-        avg_launch_s = k_times[dom] / launches
-        units_per_launch = n_units / launches
-        achieved = bpu * units_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof):
-            try:
-                traffic = json.load(open(prof)).get(args.workload, {}).get(dom + "_bytes_per_launch")
-            except Exception:
-                traffic = None
-        per_kernel = {k: {"seconds": k_times[k], "units": units[k][0], "bytes_per_unit": units[k][1], "launches": units[k][2],
-                          "GBps": (units[k][0] * units[k][1] / k_times[k] / 1e9) if k_times[k] > 0 else 0.0} for k in units}
+        scene_rel, W, H, spp1, gi = WORKLOADS[args.workload]
         out = {
             "metric": "Mrays/s (closest-hit + any-hit rays per second), with wall-clock per frame",
-            "value": rays_total / elapsed / 1e6,
+            "value": head["value"],
             "unit": "Mrays/s",
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{os.path.basename(scene_rel)} {W}x{H}, {spp} spp ({spp1} per GPU), GI depth {gi}, "
-                                   f"internal bounces 16, keyed RNG seed 0, {tile}x{tile} interleaved tiles over {N} GPU(s)",
-                       "rays_per_frame": rays_total / args.steps, "camera_samples_per_frame": samples_total / args.steps,
+            "config": {"workload": head["workload"], "rays_per_frame": head["rays_per_frame"],
+                       "camera_samples_per_frame": head["camera_samples_per_frame"],
                        "framebuffer_gather": "one rccl all_gather of packed tiles (float radiance + rgb8), native pack/unpack kernels" if N > 1 else "none"},
-            "photon_build_s": photon_build_s, "photon_gather_s_per_frame": (agg.get("reserved0", 0.0) / args.steps) if photon_build_s else None,
-            "photon_heap_pass_s_per_frame": (agg.get("reserved1", 0.0) / args.steps) if photon_build_s else None,
-            "photon_heap_queries_per_frame": (agg.get("reserved2", 0.0) / args.steps) if photon_build_s else None,
-            "photon_wave_queries_per_frame": (agg.get("reserved3", 0.0) / args.steps) if photon_build_s else None,
-            "kernel_seconds": k_times, "timers": {0: "k_shade only", 1: "every kernel group", -1: "none"}.get(opts.timers),
-            "kernels": per_kernel,
-            "wave_steps_per_frame": agg["wave_iterations"] / args.steps,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "avg_launch_ms": avg_launch_s * 1e3, "units_per_launch": units_per_launch,
-                         "bytes_per_unit": bpu,
-                         "note": "scene is cache-resident; traversal/shading are latency- and ALU-bound, not HBM-bound (DESIGN.md)"},
+            "kernel_seconds": head["kernel_seconds"], "timers": head["timers"], "kernels": head["kernels"],
+            "wave_steps_per_frame": head["wave_steps_per_frame"],
+            "roofline": head["roofline"],
         }
+        if "photon" in head:
+            out["photon"] = head["photon"]
+        if configs:
+            out["configs"] = configs
         if N == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene_path, spp1, gi)
+            out["cpu_baseline"] = cpu_baseline(os.path.join(ROOT, scene_rel), spp1, gi)
         print(json.dumps(out), flush=True)
     if N > 1:
         dist.barrier()

@@ -41,15 +41,13 @@ class Stats(C.Structure):
                 ("seconds_total", C.c_double), ("seconds_trace_closest", C.c_double),
                 ("seconds_trace_shadow", C.c_double), ("seconds_shade", C.c_double), ("seconds_other", C.c_double),
                 ("launches_trace_closest", C.c_uint64), ("launches_trace_shadow", C.c_uint64),
+                ("seconds_photon_gather", C.c_double), ("seconds_photon_heavy", C.c_double),
+                ("photon_queries", C.c_uint64), ("photon_heavy_queries", C.c_uint64), ("photon_wave_queries", C.c_uint64),
+                ("photon_exact_queries", C.c_uint64), ("photon_nodes_visited", C.c_uint64),
                 ("reserved", C.c_double * 4)]
 
     def as_dict(self):
-        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
-        d["reserved0"] = self.reserved[0]  # seconds in the photon gather
-        d["reserved1"] = self.reserved[1]  # ... of which in the candidate-heap pass
-        d["reserved2"] = self.reserved[2]  # queries that needed the candidate heap
-        d["reserved3"] = self.reserved[3]  # queries walked by a whole wave
-        return d
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
 
 
 class Hits(C.Structure):

@@ -265,7 +265,7 @@ __device__ inline void photon_finish(V3 sumI, V3 sumD, float d2max, V3 &irrad, V
 // met: the caller redoes this query with photon_estimate_heap (the sums then run in heap-array order); 3 = more than
 // `budget` photons visited without an answer: the caller hands the query to a whole wave (k_photon_gather_wave), so
 // that one lane's long walk (a dense cluster inside the radius, most of it rejected) does not hold up its launch.
-__device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 normal, float radius, int budget, V3 &irrad, V3 &direction)
+__device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 normal, float radius, int budget, V3 &irrad, V3 &direction, uint32_t &visited)
 {
     irrad = v3(0, 0, 0);
     direction = v3(0, 0, 0);
@@ -278,6 +278,7 @@ __device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 nor
     float4 h;
     while (!w.done) {
         if (!photon_walk_step(M, w, pos, d2max, node, h)) continue;
+        visited++;
         if (--budget < 0) return 3;
         const float dist2 = length_sq(v3(h.x, h.y, h.z) - pos);
         if (dist2 < d2max) {
@@ -323,7 +324,7 @@ __device__ inline unsigned long long photon_walk_rank(const PhotonMapDev &M, V3 
     }
     return key | (2ull << (62 - 2 * depth));
 }
-__device__ inline int photon_estimate_wave(const PhotonMapDev &M, WaveGatherLds &L, V3 pos, V3 normal, float radius, V3 &irrad, V3 &direction)
+__device__ inline int photon_estimate_wave(const PhotonMapDev &M, WaveGatherLds &L, V3 pos, V3 normal, float radius, V3 &irrad, V3 &direction, uint32_t &visited /* lane 0's */)
 {
     const uint32_t lane = threadIdx.x;
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -337,6 +338,7 @@ __device__ inline int photon_estimate_wave(const PhotonMapDev &M, WaveGatherLds 
     while (top > 0) {
         const uint32_t take = top < 64u ? top : 64u;
         top -= take;
+        visited += take;
         bool push_near = false, push_far = false, accept = false;
         uint32_t nearc = 0, me = 0;
         if (lane < take) {
@@ -421,7 +423,7 @@ __device__ inline void cand_pair(const unsigned long long *cand, int j, unsigned
     c0 = v.x; c1 = v.y;
 }
 __device__ inline bool photon_estimate_heap(const PhotonMapDev &M, V3 pos, V3 normal, float radius, unsigned long long *cand, size_t /*stride = 1*/,
-                                            V3 &irrad, V3 &direction)
+                                            V3 &irrad, V3 &direction, uint32_t &visited)
 {
     // The walk advances by uniform steps (photon_walk_step); the sift-downs stay inner loops.  (Tried and slower: every sift
     // LEVEL as a step of one flat loop, +27 %; a two-phase loop "all lanes walk to their next candidate, then sift
@@ -437,6 +439,7 @@ __device__ inline bool photon_estimate_heap(const PhotonMapDev &M, V3 pos, V3 no
         int node;
         float4 h;
         if (!photon_walk_step(M, w, pos, d2max, node, h)) continue;
+        visited++;
         const float dist2 = length_sq(v3(h.x, h.y, h.z) - pos);
         if (!(dist2 < d2max)) continue;
         const float4 c0 = M.cold[2 * (size_t)node];

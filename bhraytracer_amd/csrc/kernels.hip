@@ -1192,23 +1192,30 @@ __device__ inline void wave_append(bool flag, uint32_t value, uint32_t *list, ui
     base = __shfl(base, __ffsll((long long)m) - 1);
     if (flag) list[base + (uint32_t)__popcll(m & ((1ull << __lane_id()) - 1ull))] = value;
 }
+// kd-tree nodes examined by the gather (bhrt_stats.photon_nodes_visited): one 64-bit atomic per wave
+__device__ inline void count_visited(uint32_t visited, uint32_t *counts)
+{
+    for (int off = 32; off > 0; off >>= 1) visited += __shfl_xor(visited, off);
+    if (__lane_id() == 0 && visited) atomicAdd((unsigned long long *)(counts + 2), (unsigned long long)visited);
+}
 template <class Sink>
 __global__ void __launch_bounds__(kBlock) k_photon_gather_fast(Sink sink, uint32_t q0, uint32_t cnt, const uint32_t *order, PhotonMapDev M, float radius,
-                                                               int lane_budget, uint32_t *heavy, uint32_t *longq, uint32_t *counts /* [0] heavy, [1] long */)
+                                                               int lane_budget, uint32_t *heavy, uint32_t *longq, uint32_t *counts /* [0] heavy, [1] long, [2..3] visited */)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     int r = 0;
-    uint32_t q = 0;
+    uint32_t q = 0, visited = 0;
     if (i < cnt) {
         q = order ? order[i] : q0 + i;
         if (!sink.skip(q)) {
             V3 irr, d;
-            r = photon_estimate_fast(M, sink.pos(q), sink.nrm(q), radius, lane_budget, irr, d);
+            r = photon_estimate_fast(M, sink.pos(q), sink.nrm(q), radius, lane_budget, irr, d, visited);
             if (r < 2) sink.done(q, r == 1, irr, d);
         }
     }
     wave_append(r == 2, q, heavy, &counts[0]);
     wave_append(r == 3, q, longq, &counts[1]);
+    count_visited(visited, counts);
 }
 // Pass 2: the long walks, one wave per query (photon_estimate_wave); blocks stride over the list until it is exhausted.
 template <class Sink>
@@ -1216,28 +1223,33 @@ __global__ void __launch_bounds__(64) k_photon_gather_wave(Sink sink, const uint
 {
     __shared__ WaveGatherLds lds;
     const uint32_t n_long = counts[1];
+    uint32_t visited = 0;
     for (uint32_t i = blockIdx.x; i < n_long; i += gridDim.x) {
         const uint32_t q = longq[i];
         V3 irr, d;
-        const int r = photon_estimate_wave(M, lds, sink.pos(q), sink.nrm(q), radius, irr, d);
+        const int r = photon_estimate_wave(M, lds, sink.pos(q), sink.nrm(q), radius, irr, d, visited);
         if (threadIdx.x == 0) {
             if (r >= 2) heavy[atomicAdd(&counts[0], 1u)] = q;
             else sink.done(q, r == 1, irr, d);
         }
         __syncthreads();
     }
+    if (threadIdx.x == 0 && visited) atomicAdd((unsigned long long *)(counts + 2), (unsigned long long)visited);
 }
 // Pass 3: the queries of heavy[h0, h0+cnt) with the full candidate heap, one scratch column per lane.
 template <class Sink>
 __global__ void __launch_bounds__(kBlock) k_photon_gather_heap(Sink sink, const uint32_t *heavy, uint32_t h0, uint32_t cnt, PhotonMapDev M, float radius,
-                                                               unsigned long long *scr, size_t stride)
+                                                               unsigned long long *scr, size_t stride, uint32_t *counts)
 {
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= cnt) return;
-    const uint32_t q = heavy[h0 + lane];
-    V3 irr, d;
-    const bool found = photon_estimate_heap(M, sink.pos(q), sink.nrm(q), radius, scr + (size_t)lane * BHRT_HEAP_COLUMN, 1, irr, d);
-    sink.done(q, found, irr, d);
+    uint32_t visited = 0;
+    if (lane < cnt) {
+        const uint32_t q = heavy[h0 + lane];
+        V3 irr, d;
+        const bool found = photon_estimate_heap(M, sink.pos(q), sink.nrm(q), radius, scr + (size_t)lane * BHRT_HEAP_COLUMN, 1, irr, d, visited);
+        sink.done(q, found, irr, d);
+    }
+    count_visited(visited, counts);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1535,8 +1547,8 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
         D->heavy_cap = cnt;
     }
     if (!D->d_n_heavy) {
-        HIP_CHECK(hipMalloc(&D->d_n_heavy, 2 * sizeof(uint32_t)));
-        HIP_CHECK(hipHostMalloc(&D->h_n_heavy, 2 * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&D->d_n_heavy, 4 * sizeof(uint32_t))); // [0] heavy, [1] long, [2..3] nodes visited (64-bit)
+        HIP_CHECK(hipHostMalloc(&D->h_n_heavy, 4 * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc(&D->d_cells, (size_t)BHRT_GATHER_CELLS * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc(&D->d_tile_sums, (size_t)(BHRT_GATHER_CELLS / kScanTile + kScanBlock) * sizeof(uint32_t)));
     }
@@ -1565,7 +1577,7 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
         n_walk = D->h_n_heavy[0];
         grid = dim3((n_walk + kBlock - 1) / kBlock);
     }
-    HIP_CHECK(hipMemsetAsync(D->d_n_heavy, 0, 2 * sizeof(uint32_t), D->stream));
+    HIP_CHECK(hipMemsetAsync(D->d_n_heavy, 0, 4 * sizeof(uint32_t), D->stream));
     int lane_budget = BHRT_GATHER_LANE_BUDGET;
     if (const char *e = getenv("BHRT_GATHER_LANE_BUDGET")) lane_budget = std::max(1, atoi(e)); // test knob: a tiny budget sends every query through pass 2
     if (n_walk > 0) {
@@ -1574,23 +1586,34 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_wave<Sink>), dim3(std::min<uint32_t>(n_walk, 2048u)), dim3(64), 0, D->stream, sink, D->d_long, D->pm, radius,
                            D->d_heavy, D->d_n_heavy);
     }
-    HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_n_heavy, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
+    HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_n_heavy, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
     HIP_CHECK(hipStreamSynchronize(D->stream));
     const uint32_t n_heavy = D->h_n_heavy[0];
-    if (st) st->reserved[3] += (double)D->h_n_heavy[1];
+    if (st) {
+        st->photon_queries += cnt;
+        st->photon_wave_queries += D->h_n_heavy[1];
+        st->photon_heavy_queries += n_heavy;
+        st->photon_nodes_visited += (uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32);
+    }
     if (n_heavy == 0) return BHRT_OK;
     const uint32_t heap_lanes = 1u << 20; // as many heaps in flight as possible: the pass is a chain of dependent accesses per query (65 k lanes: 1.8x slower)
     int rc = EnsurePhotonScratch(D, std::min<uint32_t>(heap_lanes, (n_heavy + 4095u) & ~4095u));
     if (rc) return rc;
-    Timer t(D, st ? &st->reserved[1] : nullptr, 0);
+    Timer t(D, st ? &st->seconds_photon_heavy : nullptr, 0);
+    HIP_CHECK(hipMemsetAsync(D->d_n_heavy + 2, 0, 2 * sizeof(uint32_t), D->stream));
     const uint32_t chunk = std::min<uint32_t>(D->scr_lanes, heap_lanes);
     for (uint32_t h0 = 0; h0 < n_heavy; h0 += chunk) {
         const uint32_t m = std::min<uint32_t>(chunk, n_heavy - h0);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_heap<Sink>), dim3((m + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, sink, D->d_heavy, h0, m,
-                           D->pm, radius, D->d_scr, (size_t)D->scr_lanes);
+                           D->pm, radius, D->d_scr, (size_t)D->scr_lanes, D->d_n_heavy);
     }
     t.Stop();
-    if (st) st->reserved[2] += (double)n_heavy;
+    if (st) {
+        st->photon_exact_queries += n_heavy;
+        HIP_CHECK(hipMemcpyAsync(D->h_n_heavy + 2, D->d_n_heavy + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
+        HIP_CHECK(hipStreamSynchronize(D->stream));
+        st->photon_nodes_visited += (uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32);
+    }
     return BHRT_OK;
 }
 
@@ -1758,7 +1781,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             // caustic term (MtlBlinn.cpp:329-342) of every frame of the pass in ONE gather: a gather launch lasts as long as its
             // longest query (15-80 ms for a query that fills the 1000-candidate heap), so a gather per wave step — 23 steps
             // per pass, most with a few hundred frames — spent 2 s per frame waiting for single lanes
-            Timer t(D, &st->reserved[0], 0);
+            Timer t(D, &st->seconds_photon_gather, 0);
             const GatherToFrames sink = {F, D->S.materials};
             int rc = RunGather(D, sink, 0, frame_marks.back(), 0.5f /* MAX_Area, MtlBlinn.cpp:29 */, st);
             if (rc) return rc;

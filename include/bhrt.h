@@ -80,7 +80,15 @@ typedef struct bhrt_stats {
     double seconds_total;    /* wall clock of the call, scene already resident */
     double seconds_trace_closest, seconds_trace_shadow, seconds_shade, seconds_other; /* HIP-event kernel time */
     uint64_t launches_trace_closest, launches_trace_shadow;
-    double reserved[4]; /* [0] = seconds in the photon gather (all of it), [1] = of which in the candidate-heap pass, [2] = queries that needed it, [3] = queries walked by a whole wave */
+    /* caustic gather (EstimateIrradiance<1000>, DataStructure/cyPhotonMap.h:332-382; called at MtlBlinn.cpp:334) */
+    double seconds_photon_gather;  /* wall clock of the gather of every pass, HIP events */
+    double seconds_photon_heavy;   /* ... of which in the pass for queries with >= 1000 photons inside the radius */
+    uint64_t photon_queries;       /* Shade() frames that asked for the caustic term */
+    uint64_t photon_heavy_queries; /* queries that met 1000 photons */
+    uint64_t photon_wave_queries;  /* queries whose walk was handed to a whole wave */
+    uint64_t photon_exact_queries; /* heavy queries answered by the exact replay of the reference's candidate heap */
+    uint64_t photon_nodes_visited; /* kd-tree nodes whose photon was examined (24 B each: SURVEY.md 8d) */
+    double reserved[4];
 } bhrt_stats;
 
 /* compact hit record written by the trace kernel (SoA on the device: one array per field) */

@@ -350,12 +350,14 @@ int main(int argc, char **argv)
         else cmds.push_back(s);
     }
     omp_set_num_threads(1);
+    const double t_start = omp_get_wtime();
     if (!LoadScene(scene)) return 1;
     SetupCameraFrame();
     CalculateLightsIntensity(); // Main.cpp:116-123 (sorts `lights`, sums allLightIntensity)
     Flatten(&rootNode, -1, 1);
     const int W = camera.imgWidth, H = camera.imgHeight;
     if (rx1 < 0) { rx1 = W; ry1 = H; }
+    const double t_loaded = omp_get_wtime();
 
     for (const std::string &cmd : cmds) {
         if (cmd == "dump") {
@@ -515,6 +517,8 @@ int main(int argc, char **argv)
             usage();
         }
     }
+    // bench.py's cpu_baseline reads this line: scene load (XML, OBJ, BVH build) apart from the commands themselves
+    fprintf(stderr, "ref_harness: load %.6f s, commands %.6f s\n", t_loaded - t_start, omp_get_wtime() - t_loaded);
     fprintf(stderr, "ref_harness: done (%llu rand() draws)\n", g_draws);
     return 0;
 }

@@ -12,7 +12,20 @@ SCENES = os.path.join(ROOT, "tests", "scenes")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 REFERENCE = "/root/reference/BHRayTracer"
 REF_HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
-GOLDEN_CASES = ["c1_sphere_plane", "c2_glass_small", "c3_mesh_small", "c4_textured"]
+GOLDEN_CASES = ["c1_sphere_plane", "c2_glass_small", "c3_mesh_small", "c4_textured", "c3_room_small"]
+# BASELINE's full sizes, pinned by the compiled reference as well: the closed-room mesh scene at 1920x1080 and
+# BASELINE config 4's 3840x2160 frame; both use the 100,352-triangle mesh that tools/gen_mesh.py writes on demand
+FULL_SIZE_CASES = ["c3_room", "c4_mesh_4k"]
+
+
+def ensure_mesh(n=224):
+    """tests/scenes/gen/mesh_<n>.obj (deterministic generator, no RNG; git-ignored)."""
+    path = os.path.join(SCENES, "gen", f"mesh_{n}.obj")
+    if not os.path.exists(path):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import gen_mesh
+        gen_mesh.generate(path, n)
+    return path
 
 
 def pytest_configure(config):
@@ -48,6 +61,8 @@ def load_scene(B):
     def _load(name):
         path = name if os.path.isabs(name) else os.path.join(SCENES, name if name.endswith(".xml") else name + ".xml")
         if path not in _scene_cache:
+            if "gen/mesh_224.obj" in open(path).read():
+                ensure_mesh(224)
             _scene_cache[path] = B.Scene(path)
         return _scene_cache[path]
     return _load

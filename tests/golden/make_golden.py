@@ -16,7 +16,8 @@ The reference has no tests or golden vectors of its own, s
 
   aux_images          RenderImage's z-buffer + ComputeZBufferImage, first-hit normal / albedo, colorArray (post-gamma floats)
 
-`make_golden.py global_photon` / `make_golden.py aux_images` regenerate only that file.
+`make_golden.py global_photon` / `make_golden.py aux_images` regenerate only that file; `make_golden.py case <name>...` only
+the named scene cases.
 """
 import hashlib
 import os
@@ -38,7 +39,13 @@ CASES = {
     "c2_glass_small": ("c2_glass_small.xml", (120, 110, 184, 158), 4, 3),
     "c3_mesh_small": ("c3_mesh_small.xml", (110, 70, 174, 118), 4, 3),
     "c4_textured": ("c4_textured.xml", (100, 90, 164, 138), 4, 2),
+    # the Cornell room of proj13.xml with a glass mesh in the teapot's place (SURVEY.md 8d, C3 closed room): small, committed mesh
+    "c3_room_small": ("c3_room_small.xml", (136, 96, 200, 144), 4, 3),
+    # ... and BASELINE's full sizes (the 100,352-triangle mesh of tools/gen_mesh.py, generated on demand under tests/scenes/gen/):
+    "c3_room": ("c3_room.xml", (980, 500, 1028, 532), 2, 3),          # 1920x1080 closed room
+    "c4_mesh_4k": ("c4_mesh_4k.xml", (1700, 900, 1748, 932), 2, 3),   # BASELINE config 4: 3840x2160
 }
+FULL_SIZE = ("c3_room", "c4_mesh_4k")
 
 
 def sha(a):
@@ -65,14 +72,23 @@ def main():
         {"global_photon": global_photon_case, "aux_images": aux_case}[sys.argv[1]](tmp)
         subprocess.run(["rm", "-rf", tmp])
         return
+    only = sys.argv[2:] if sys.argv[1:2] == ["case"] else None
     for name, (xml, region, spp, gi) in CASES.items():
+        if only is not None and name not in only:
+            continue
+        if name in FULL_SIZE:
+            mesh = os.path.join(SCENES, "gen", "mesh_224.obj")
+            if not os.path.exists(mesh):
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import gen_mesh
+                gen_mesh.generate(mesh, 224)
         pre = os.path.join(tmp, name)
         run(xml, pre, "dump", "primary")
         cam = np.fromfile(pre + ".camera_f32", np.float32)
         W, H = int(cam[11]), int(cam[12])
         pi = np.fromfile(pre + ".primary_i32", np.int32).reshape(H, W, 2)
         pf = np.fromfile(pre + ".primary_f32", np.float32).reshape(H, W, 16)
-        step = 8 if W > 400 else 4
+        step = 16 if W > 1000 else 8 if W > 400 else 4
         sub = (slice(None, None, step), slice(None, None, step))
         out = {
             "width": W, "height": H, "primary_step": step,
@@ -120,9 +136,10 @@ def main():
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
         print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {int((pi[..., 0] >= 0).sum())}/{W * H} primary hits")
-    photon_case(tmp)
-    global_photon_case(tmp)
-    aux_case(tmp)
+    if only is None:
+        photon_case(tmp)
+        global_photon_case(tmp)
+        aux_case(tmp)
     subprocess.run(["rm", "-rf", tmp])
 
 
@@ -162,7 +179,8 @@ def aux_case(tmp):
     on the z-buffer the commented-out store of Main.cpp:231 would fill; HitInfo::N and MtlBlinn's diffuse.Sample(uvw, duvw) of
     the first hit (the optional DenoiseImage inputs, Main.cpp:70-71); colorArray (Main.cpp:202,229) of the render region."""
     out = {}
-    for name, (xml, region, spp, gi) in CASES.items():
+    for name in ("c1_sphere_plane", "c2_glass_small", "c3_mesh_small", "c4_textured"):
+        xml, region, spp, gi = CASES[name]
         pre = os.path.join(tmp, "aux_" + name)
         x0, y0, x1, y1 = region
         run(xml, pre, "--spp", spp, "--gi", gi, "--region", x0, y0, x1, y1, "aux", "render")

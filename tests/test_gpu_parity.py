@@ -272,7 +272,8 @@ def test_several_mesh_nodes_park_and_resume(gpu, B, O, tmp_path):
 
 # ---------------------------------------------------------------------------------------------------- radiance
 @pytest.mark.parametrize("case,spp,gi", [("c1_sphere_plane", 3, 3), ("c2_glass_small", 4, 3), ("c3_mesh_small", 3, 3),
-                                         ("c4_textured", 3, 2), ("c2_glass_small", 2, 0), ("c2_glass_small", 2, -1)])
+                                         ("c4_textured", 3, 2), ("c2_glass_small", 2, 0), ("c2_glass_small", 2, -1),
+                                         ("c3_room_small", 3, 3)])
 def test_per_sample_radiance_vs_oracle(case, spp, gi, gpu, load_scene, O):
     sc = load_scene(case)
     W, H = sc.width, sc.height

@@ -6,14 +6,14 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, same_bits
+from conftest import FULL_SIZE_CASES, GOLDEN_CASES, same_bits
 
 
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("case", GOLDEN_CASES + FULL_SIZE_CASES)
 def test_primary_hit_table(case, load_scene, golden, O):
     g = golden(case)
     sc = load_scene(case)
@@ -34,7 +34,7 @@ def test_primary_hit_table(case, load_scene, golden, O):
     assert same_bits(a[..., 10:16][hit], g["primary_duvw"][hit])    # ray differentials (planes)
 
 
-@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("case", GOLDEN_CASES + FULL_SIZE_CASES)
 @pytest.mark.parametrize("side", [1, 2, 3])
 def test_secondary_rays_all_hit_sides(case, side, load_scene, golden, O):
     g = golden(case)
@@ -47,7 +47,7 @@ def test_secondary_rays_all_hit_sides(case, side, load_scene, golden, O):
     assert np.array_equal(r["front"][hit], g[f"rays_front_{side}"][hit])
 
 
-@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("case", GOLDEN_CASES + FULL_SIZE_CASES)
 def test_shadow_rays(case, load_scene, golden, O):
     g = golden(case)
     sc = load_scene(case)
@@ -56,7 +56,7 @@ def test_shadow_rays(case, load_scene, golden, O):
     assert 0 < (vis == 0).sum() < len(vis)
 
 
-@pytest.mark.parametrize("case", GOLDEN_CASES)
+@pytest.mark.parametrize("case", GOLDEN_CASES + FULL_SIZE_CASES)
 def test_integrator_per_sample_radiance(case, load_scene, golden, O):
     g = golden(case)
     sc = load_scene(case)
