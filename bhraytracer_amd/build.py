@@ -59,5 +59,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_variant(name: str, defines) -> str:
+    """Experiment aid: the same library with extra -D flags on the HIP TUs, as bhraytracer_amd/_variants/libbhrt_<name>.so
+    (load it with BHRT_LIB=<path>; A/B runs of one kernel change on the GPU box).  Not part of build()."""
+    vdir = os.path.join(HERE, "_variants")
+    os.makedirs(vdir, exist_ok=True)
+    build(verbose=False)  # host objects
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    objs = [os.path.join(OUT, s + ".o") for s in HOST_SRCS]
+    for s in HIP_SRCS:
+        obj = os.path.join(vdir, f"{name}_{s}.o")
+        _run([hipcc, "--offload-arch=gfx950"] + COMMON + ["-Wno-unused-result", "-Wno-pass-failed"] + list(defines) + ["-c", os.path.join(CSRC, s), "-o", obj])
+        objs.append(obj)
+    lib = os.path.join(vdir, f"libbhrt_{name}.so")
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lz", "-o", lib])
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--variant" in sys.argv:
+        k = sys.argv.index("--variant")
+        build_variant(sys.argv[k + 1], sys.argv[k + 2:])
+    else:
+        build(force="--force" in sys.argv)

@@ -300,6 +300,26 @@ __device__ inline bool parked_entry(const RayOrder &ord, uint32_t b, uint32_t *s
     i = active ? ord.idx[((size_t)RC_MESH * BHRT_ORDER_SHARDS + seg) * ord.shard_cap + local] : 0xffffffffu;
     return true;
 }
+// XCD-local launch order (a speed choice, never correctness: MI355X_MICROARCH.md "Workgroup dispatch, XCD placement").  Workgroups are
+// dealt round-robin over the 8 XCDs, so blocks b and b + 8 share an XCD and its 4 MiB L2.  With the work slices of a sorted list taken
+// in blockIdx order every L2 sees every eighth slice of the range in flight.  BHRT_XCD_LOCAL = G > 0: within every run of 8 G slices
+// the blocks of one XCD take G consecutive slices instead (the last, partial run keeps blockIdx order).  0 = blockIdx order.
+// Measured: one contiguous eighth of the whole list per XCD — the largest G — costs more than it saves: the cost
+// along a sorted list is anything but uniform (one XCD ends up with the photon focus, or with the octant most rays travel in).
+// false: this block has no slice.
+#ifndef BHRT_XCD_LOCAL
+#define BHRT_XCD_LOCAL 0
+#endif
+__device__ inline bool xcd_slice(uint32_t b, uint32_t nb, uint32_t &slice)
+{
+    slice = b;
+#if BHRT_XCD_LOCAL
+    constexpr uint32_t G = BHRT_XCD_LOCAL, span = 8 * G;
+    const uint32_t chunk = b / span, in = b % span;
+    if ((chunk + 1) * span <= nb) slice = chunk * span + (in & 7u) * G + (in >> 3);
+#endif
+    return b < nb;
+}
 // counting sort of the parked rays by coherence key: histogram (k_trace_closest, as it parks), scan (k_scan_*), scatter.  A fixed grid strides over
 // the slices: the number of parked rays is only known on the device, and a grid sized for "all rays parked" spends
 // most of a launch retiring empty workgroups.
@@ -326,16 +346,18 @@ __global__ void __launch_bounds__(kBlock, 6) k_trace_mesh(DevScene S, PassInfo P
     __shared__ uint32_t s_seg;
     bool active;
     uint32_t i;
+    uint32_t slice;
     if (kCamera) {
         // camera rays are parked in slot order (pixel-major, all samples of a pixel together): already coherent, so the
         // list is taken as filed and the key sort (2.6 ms per pass for 66 M slots) is skipped
-        if (!parked_entry(ord, blockIdx.x, &s_seg, i)) return; // uniform per workgroup
+        if (!xcd_slice(blockIdx.x, ord.mesh_start[BHRT_ORDER_SHARDS], slice)) return; // uniform per workgroup
+        if (!parked_entry(ord, slice, &s_seg, i)) return;
         active = i != 0xffffffffu;
         if (!active) i = 0;
     } else {
         const uint32_t total = ord.mesh_count[BHRT_ORDER_SHARDS];
-        if (blockIdx.x * kBlock >= total) return; // uniform per workgroup
-        const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+        if (!xcd_slice(blockIdx.x, (total + kBlock - 1) / kBlock, slice)) return; // uniform per workgroup
+        const uint32_t k = slice * kBlock + threadIdx.x;
         active = k < total;
         i = active ? ord.park_sorted[k] : 0u;
     }
@@ -354,7 +376,7 @@ __global__ void __launch_bounds__(kBlock, 6) k_trace_mesh(DevScene S, PassInfo P
                                kPath ? path + threadIdx.x : (PathT *)nullptr, kBlock, kMeshNodelet);
     if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; }
     // key-sorted rays are filed for shading by k_file_parked, in queue order instead of traversal order
-    if (kCamera) file_ray(active ? shading_class(meta, hit) : (uint32_t)RC_NONE, i, blockIdx.x & (BHRT_ORDER_SHARDS - 1), ord, cnt);
+    if (kCamera) file_ray(active ? shading_class(meta, hit) : (uint32_t)RC_NONE, i, slice & (BHRT_ORDER_SHARDS - 1), ord, cnt);
 }
 // Files the finished mesh rays of a later wave step under their shading class, walking the parked list as it was filed
 // (queue order): k_shade then reads rays, hits and parent frames of neighbouring queue slots together (filed in the
@@ -407,8 +429,9 @@ __global__ void __launch_bounds__(kBlock) k_shadow_mesh(DevScene S, ShadowQueue 
     typedef typename std::conditional<kPath == 2, uint32_t, uint16_t>::type PathT;
     __shared__ uint32_t s_seg;
     __shared__ PathT path[kPath ? 33 * kBlock : 1];
-    uint32_t i;
-    if (!parked_entry(ord, blockIdx.x, &s_seg, i)) return;
+    uint32_t i, slice;
+    if (!xcd_slice(blockIdx.x, ord.mesh_start[BHRT_ORDER_SHARDS], slice)) return;
+    if (!parked_entry(ord, slice, &s_seg, i)) return;
     if (i == 0xffffffffu) return;
     vis[q.frame[i]] = trace_shadow_t<2, PathT>(S, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), q.tmax[i], kPath ? path + threadIdx.x : (PathT *)nullptr, kBlock);
 }
@@ -1202,7 +1225,9 @@ template <class Sink>
 __global__ void __launch_bounds__(kBlock) k_photon_gather_fast(Sink sink, uint32_t q0, uint32_t cnt, const uint32_t *order, PhotonMapDev M, float radius,
                                                                int lane_budget, uint32_t *heavy, uint32_t *longq, uint32_t *counts /* [0] heavy, [1] long, [2..3] visited */)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t slice;
+    xcd_slice(blockIdx.x, gridDim.x, slice); // cell-sorted order: one contiguous eighth of it per XCD
+    const uint32_t i = slice * blockDim.x + threadIdx.x;
     int r = 0;
     uint32_t q = 0, visited = 0;
     if (i < cnt) {

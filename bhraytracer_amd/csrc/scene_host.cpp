@@ -1062,6 +1062,14 @@ int LoadSceneXml(const char *path, FlatScene &out, std::string &err, int bvh_dev
         o.off_leaf_tris = W.Append(leaf_tris.data(), leaf_tris.size() * sizeof(bhrt_tri));
         memcpy(o.bound_min, m.bound_min, 12);
         memcpy(o.bound_max, m.bound_max, 12);
+        o.bvh_nested = 1; // see bhrt_flat.h: checked, not assumed
+        for (uint32_t n = 1; n < o.n_bvh_nodes && o.bvh_nested; n++) {
+            const bhrt_bvh_node &pn = m.bvh[n];
+            if (pn.data & 0x80000000u) continue;
+            for (uint32_t c = pn.data & 0x7fffffffu, e = c + 2; c < e && c < o.n_bvh_nodes; c++)
+                for (int k = 0; k < 3; k++)
+                    if (!(m.bvh[c].b[k] >= pn.b[k] && m.bvh[c].b[k + 3] <= pn.b[k + 3])) o.bvh_nested = 0;
+        }
     }
     H.n_meshes = (uint32_t)meshes.size();
 

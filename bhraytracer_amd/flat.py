@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 MAGIC = 0x54524842
-VERSION = 7
+VERSION = 8
 BIGFLOAT = np.float32(1.0e30)
 
 OBJ_NONE, OBJ_SPHERE, OBJ_PLANE, OBJ_MESH = 0, 1, 2, 3
@@ -33,7 +33,7 @@ class Mesh(C.Structure):
                 ("off_v", C.c_uint64), ("off_vn", C.c_uint64), ("off_vt", C.c_uint64),
                 ("off_f", C.c_uint64), ("off_fn", C.c_uint64), ("off_ft", C.c_uint64),
                 ("off_bvh", C.c_uint64), ("off_elems", C.c_uint64), ("off_tris", C.c_uint64), ("off_dbvh", C.c_uint64), ("off_leaf_tris", C.c_uint64),
-                ("bound_min", C.c_float * 3), ("bound_max", C.c_float * 3)]
+                ("bound_min", C.c_float * 3), ("bound_max", C.c_float * 3), ("bvh_nested", C.c_uint32), ("pad0", C.c_uint32)]
 
 
 class TexMap(C.Structure):

@@ -20,7 +20,7 @@
 #include <stdint.h>
 
 #define BHRT_FLAT_MAGIC 0x54524842u /* "BHRT" */
-#define BHRT_FLAT_VERSION 7u
+#define BHRT_FLAT_VERSION 8u
 #define BHRT_MAX_NODE_DEPTH 8 /* scene-graph depth below the root the kernels support */
 #define BHRT_BIGFLOAT 1.0e30f  /* Scenes/scene.h:38 */
 
@@ -87,6 +87,12 @@ typedef struct bhrt_mesh {
                                           off_bvh keeps cyBVH's own numbering (what the reference's node array looks like). */
     uint64_t off_leaf_tris;            /* bhrt_tri[nf] in BVH leaf order: entry k = triangle elems[k] (one load instead of two dependent ones) */
     float bound_min[3], bound_max[3];  /* cyTriMesh::ComputeBoundingBox */
+    uint32_t bvh_nested;               /* 1 = every child box lies inside its parent's box, float for float (true of every tree cyBVH::Build makes:
+                                          boxes are min / max over the same vertex coordinates).  Box::IntersectRay (Box.cpp:3-46) is monotone in the
+                                          box bounds, rounding included, so a ray that misses a box misses every box nested in it: TraceBVHNode's
+                                          visit of a box-missed INNER sibling (TriObj.cpp:245-248,263-266) then ends at that node's own two box
+                                          tests, and the traversal kernels may leave it out (device_trace.h) */
+    uint32_t pad0;
 } bhrt_mesh;
 
 /* TextureMap = Transformation + texture (scene.h:364-386) */

@@ -1853,3 +1853,93 @@ extern "C" int oracle_photon_gather(const float *p, const float *nrm, size_t cnt
     }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// BeginRender() as a whole program (Main.cpp:178-242), the way the reference itself runs it with one OpenMP thread: ONE
+// rand() stream for the process (libc's global state), consumed first by BuildCausticPhotonMap (Main.cpp:195-198, -DUSE_PhotonMap
+// builds) and then by the pixel loop in ITS order — `for i in [0, W)` outside, `for j in [0, H)` inside (Main.cpp:204-211),
+// PT_SampleCount samples per pixel, no reset anywhere.  Pinned against the reference's real BeginRender() / BuildCausticPhotonMap()
+// (oracle/ref_harness `beginrender`, tests/golden/begin_render.npz): this is the check that the per-(pixel, sample) form of
+// RenderT above restates the frame loop faithfully (camera frame, jitter, sample average, gamma, Color24, emission loop header).
+namespace {
+template <class M> int BeginRenderT(const Scene &S, const oracle_opts &o, uint32_t photon_budget, uint8_t *rgb8, void *photons_out, uint32_t *n_stored,
+                                    uint64_t *n_emitted, uint64_t *draws)
+{
+    const bhrt_camera &cam = S.H->camera;
+    const int W = cam.width, Hh = cam.height, spp = o.spp > 0 ? o.spp : 32;
+    uint32_t ctr = 0;
+    const uint32_t key = bhrt_photon_key_sequential(o.seed); // the one stream (ref_harness: g_key)
+    if (photon_budget) {
+        PhotonMapView &pm = g_pm_storage;
+        pm.photons.assign((size_t)photon_budget + 1, Photon());
+        memset(pm.photons.data(), 0, sizeof(Photon) * pm.photons.size());
+        pm.numStored = 0;
+        PhotonTracer<M> t(S, pm, (int)photon_budget);
+        const uint64_t emitted = t.Build(o.seed, false);
+        ctr = t.rng.ctr;
+        if (pm.numStored > 0) {
+            const float scale = 1.f / pm.numStored; // ScalePhotonPowers, Main.cpp:380
+            for (int i = 1; i <= pm.numStored; i++) pm.photons[i].power *= scale;
+        }
+        pm.photons.resize((size_t)pm.numStored + 1);
+        pm.unbalanced.assign(pm.photons.begin() + 1, pm.photons.end());
+        PreparePhotonMap(pm);
+        if (photons_out && pm.numStored) memcpy(photons_out, &pm.photons[1], sizeof(Photon) * pm.numStored);
+        if (n_stored) *n_stored = (uint32_t)pm.numStored;
+        if (n_emitted) *n_emitted = emitted;
+        g_photon_map = &pm;
+    }
+    const Vec3 topLeft(cam.top_left[0], cam.top_left[1], cam.top_left[2]);
+    const Vec3 dd_x = S.dd_x, dd_y = S.dd_y;
+    const Vec3 camPos(cam.pos[0], cam.pos[1], cam.pos[2]);
+    Textures<M> X(S);
+    Counters cnt;
+    Tracer<M> T(S, &cnt);
+    Rng rng;
+    rng.keyed = false;
+    rng.device_math = std::is_same<M, MathDevice>::value;
+    rng.key = key;
+    rng.ctr = ctr;
+    Shader<M> sh(S, T, X, rng, &cnt, photon_budget != 0);
+    for (int i = 0; i < W; i++)
+        for (int j = 0; j < Hh; j++) {
+            Vec3 pixelCenter = topLeft + (float)(i + 1 / 2) * dd_x - (float)(j + 1 / 2) * dd_y; // Main.cpp:145
+            const float pixelLen = dd_x.Length();
+            Color colorSum = Black();
+            for (int s = 0; s < spp; s++) {
+                Vec3 target = pixelCenter; // RandomPositionInPixel, Main.cpp:132-139
+                const Vec3 ux = dd_x.GetNormalized(), uy = dd_y.GetNormalized();
+                float fx = (float)(((double)rng.Rand() / (BHRT_RAND_MAX)) * 2 - 1);
+                target = target + ((ux * fx) * pixelLen) / 2.f;
+                float fy = (float)(((double)rng.Rand() / (BHRT_RAND_MAX)) * 2 - 1);
+                target = target + ((uy * fy) * pixelLen) / 2.f;
+                Ray ray;
+                ray.p = camPos;
+                ray.dir = target - camPos;
+                bool bHit = false;
+                HitInfo h;
+                T.Closest(ray, h, bHit, BHRT_HIT_FRONT);
+                if (bHit) colorSum += sh.Shade(ray, h, o.internal_bounces, o.gi_bounces, 1);
+                else colorSum += X.Sample(S.H->background, Vec3((float)i / cam.width, (float)j / cam.height, 0.0f));
+            }
+            const Color out = colorSum / (float)spp; // Main.cpp:170
+            const float inv = 1 / 2.2f;              // Main.cpp:220-230
+            const size_t pix = (size_t)j * W + i;
+            rgb8[pix * 3] = FloatToByte(M::Pow(out.r, inv));
+            rgb8[pix * 3 + 1] = FloatToByte(M::Pow(out.g, inv));
+            rgb8[pix * 3 + 2] = FloatToByte(M::Pow(out.b, inv));
+        }
+    if (draws) *draws = rng.ctr;
+    return 0;
+}
+} // namespace
+
+extern "C" int oracle_begin_render(const void *blob, const oracle_opts *opts, uint32_t photon_budget, uint8_t *rgb8, void *photons_out, uint32_t *n_stored,
+                                   uint64_t *n_emitted, uint64_t *draws)
+{
+    Scene S;
+    if (!S.Init(blob)) return 1;
+    if (!opts || !rgb8) { g_err = "null argument"; return 2; }
+    if (opts->math_mode == ORACLE_MATH_DEVICE) return BeginRenderT<MathDevice>(S, *opts, photon_budget, rgb8, photons_out, n_stored, n_emitted, draws);
+    return BeginRenderT<MathLibm>(S, *opts, photon_budget, rgb8, photons_out, n_stored, n_emitted, draws);
+}

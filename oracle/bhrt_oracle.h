@@ -80,6 +80,12 @@ int oracle_photon_attach(const void *photons, uint32_t n);  /* n balanced (heap-
 int oracle_photon_balance(const void *emitted, uint32_t n, void *balanced_out); /* PrepareForIrradianceEstimation on n records */
 int oracle_photon_gather(const float *p, const float *nrm, size_t cnt, float radius, float *irrad, float *dir);
 
+/* BeginRender() as the reference's whole program runs it with one thread (Main.cpp:178-242): one rand() stream for the photon build
+ * (photon_budget > 0: BuildCausticPhotonMap with that budget, Main.cpp:342-386, and the gather in Shade) and the pixel loop in
+ * column-major order, opts->spp samples per pixel.  rgb8: W*H*3 = RenderImage::GetPixels().  photons_out: the balanced map. */
+int oracle_begin_render(const void *blob, const oracle_opts *opts, uint32_t photon_budget, uint8_t *rgb8, void *photons_out, uint32_t *n_stored,
+                        uint64_t *n_emitted, uint64_t *draws);
+
 const char *oracle_last_error(void);
 
 #ifdef __cplusplus

@@ -104,6 +104,17 @@ def photon_build(blob: bytes, max_photons, seed=0, rng=RNG_KEYED, math=MATH_DEVI
     return out[:ns.value].copy(), unb, ne.value
 
 
+def begin_render(blob: bytes, width, height, spp=32, gi=3, bounces=16, seed=0, photon_budget=0, math=MATH_LIBM):
+    """BeginRender() as one program with one rand() stream (Main.cpp:178-242).  Returns (rgb8 (H, W, 3), balanced photons or None,
+    emissions, draws)."""
+    o = OracleOpts(spp, gi, bounces, seed, RNG_SEQUENTIAL, math, 1, 0, 0, 0, 0, 1, 1 if photon_budget else 0)
+    rgb = np.zeros((height, width, 3), np.uint8)
+    ph = np.zeros((max(photon_budget, 1), 24), np.uint8)
+    ns, ne, nd = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0)
+    _check(lib().oracle_begin_render(C.c_char_p(blob), C.byref(o), int(photon_budget), _p(rgb), _p(ph), C.byref(ns), C.byref(ne), C.byref(nd)))
+    return rgb, (ph[: ns.value].copy() if photon_budget else None), ne.value, nd.value
+
+
 def photon_build_global(blob: bytes, max_photons, seed=0, rng=RNG_KEYED, math=MATH_DEVICE):
     """BuildPhotonMap (Main.cpp:251-317): the global photon map.  Returns (balanced, emission order, emissions)."""
     o = OracleOpts(1, 0, 0, seed, rng, math, 1, 0, 0, 0, 0, 1, 0)
