@@ -16,7 +16,11 @@ The reference has no tests or golden vectors of its own, s
 
   aux_images          RenderImage's z-buffer + ComputeZBufferImage, first-hit normal / albedo, colorArray (post-gamma floats)
 
-`make_golden.py global_photon` / `make_golden.py aux_images` regenerate only that file; `make_golden.py case <name>...` only
+  begin_render        the reference's OWN BeginRender() as a whole program (ref_harness `beginrender`: nothing restated), 32 spp, one
+                      rand() stream for the process: RenderImage::GetPixels() of a 64x48 frame, and — the -DUSE_PhotonMap build — of a
+                      32x24 frame rendered after its own BuildCausticPhotonMap() (1,000,000 photons; digest of causticPhotonMap.dat)
+
+`make_golden.py global_photon` / `make_golden.py aux_images` / `make_golden.py begin_render` regenerate only that file; `make_golden.py case <name>...` only
 the named scene cases.
 """
 import hashlib
@@ -68,8 +72,8 @@ def main():
     if not os.path.exists(HARNESS):
         sys.exit("oracle/_ref/ref_harness missing: run `make -C oracle ref` in the development container")
     tmp = tempfile.mkdtemp(prefix="bhrt_golden_")
-    if sys.argv[1:] in (["global_photon"], ["aux_images"]):
-        {"global_photon": global_photon_case, "aux_images": aux_case}[sys.argv[1]](tmp)
+    if sys.argv[1:] in (["global_photon"], ["aux_images"], ["begin_render"]):
+        {"global_photon": global_photon_case, "aux_images": aux_case, "begin_render": begin_render_case}[sys.argv[1]](tmp)
         subprocess.run(["rm", "-rf", tmp])
         return
     only = sys.argv[2:] if sys.argv[1:2] == ["case"] else None
@@ -140,6 +144,7 @@ def main():
         photon_case(tmp)
         global_photon_case(tmp)
         aux_case(tmp)
+        begin_render_case(tmp)
     subprocess.run(["rm", "-rf", tmp])
 
 
@@ -197,6 +202,41 @@ def aux_case(tmp):
     path = os.path.join(HERE, "aux_images.npz")
     np.savez_compressed(path, **out)
     print(f"aux_images: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def begin_render_case(tmp):
+    """The reference's own BeginRender() (Main.cpp:178-242) — camera frame, CalculateLightsIntensity, the OpenMP pixel loop with one
+    thread (columns outside, rows inside), PathTracing at the compiled-in 32 spp / GI depth 3, gamma, Color24 — and, in the
+    -DUSE_PhotonMap build, its own BuildCausticPhotonMap() (Main.cpp:342-386: always 1,000,000 photons, written to
+    Resource/causticPhotonMap.dat under the working directory) in front of it.  rand() is interposed by ONE stream that is never
+    reset, like libc's.  The oracle's whole-program mode (oracle_begin_render) has to reproduce the pixels byte for byte."""
+    import shutil
+    work = os.path.join(tmp, "begin")
+    os.makedirs(os.path.join(work, "Resource", "Result"))
+    shutil.copy(os.path.join(SCENES, "mesh_small.obj"), work)
+    out = {}
+    for name, harness, xml in (("room", HARNESS, "begin_room.xml"), ("caustic", HARNESS_PM, "begin_caustic.xml")):
+        pre = os.path.join(work, name)
+        subprocess.run([harness, os.path.join(SCENES, xml), pre, "beginrender"], cwd=work, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        meta = np.fromfile(pre + ".begin_meta", np.uint64)
+        W, H = int(meta[1]), int(meta[2])
+        out[name + "_scene"] = xml
+        out[name + "_rgb8"] = np.fromfile(pre + ".begin_rgb8", np.uint8).reshape(H, W, 3)
+        out[name + "_draws"] = int(meta[0])
+        out[name + "_camera"] = np.fromfile(pre + ".begin_camera_f32", np.float32)  # topLeft, dd_x, dd_y, allLightIntensity
+        print(f"begin_render/{name}: {W}x{H}, {int(meta[0])} rand() draws, mean byte {out[name + '_rgb8'].mean():.2f}")
+    dat = np.fromfile(os.path.join(work, "Resource", "causticPhotonMap.dat"), np.uint8).reshape(-1, 24)
+    # byte 19 (planeAndDirZ): bit 3 always valid, bits 0-1 (split plane) valid for internal nodes (index < half), the rest uninitialised
+    half = len(dat) // 2 - 1
+    mask = np.where(np.arange(1, len(dat) + 1) < half, 0x0B, 0x08).astype(np.uint8)
+    dat[:, 19] &= mask
+    out["caustic_photons"] = len(dat)
+    out["caustic_photons_sha"] = sha(dat)
+    out["caustic_photons_every_997"] = dat[::997].copy()
+    print(f"begin_render/caustic: {len(dat)} photons in causticPhotonMap.dat")
+    path = os.path.join(HERE, "begin_render.npz")
+    np.savez_compressed(path, **out)
+    print(f"begin_render: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 GLOBAL_CASES = {"c5_caustics": 3000, "c2_glass_small": 2000, "c4_textured": 1500}

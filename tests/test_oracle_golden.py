@@ -66,3 +66,37 @@ def test_integrator_per_sample_radiance(case, load_scene, golden, O):
     assert same_bits(r["samples"], g["render_samples"])
     assert same_bits(r["radiance"].reshape(-1, 3), g["render_radiance"])
     assert np.array_equal(r["rgb8"].reshape(-1, 3), g["render_rgb8"])
+
+
+# ---------------------------------------------------------------------------------------------------- the whole program
+def test_whole_program_begin_render_vs_the_reference_s_own(load_scene, golden, O):
+    """oracle_begin_render against RenderImage::GetPixels() after the reference's OWN BeginRender() (Main.cpp:178-242; harness
+    command `beginrender`, which restates nothing): one rand() stream for the process, pixel loop in the reference's order, 32 spp,
+    GI depth 3.  The same number of rand() draws and the same bytes.  This is what ties the per-(pixel, sample) restatement used
+    everywhere else (camera frame, RandomPositionInPixel, sample average, gamma, Color24) to the real function."""
+    g = golden("begin_render")
+    sc = load_scene(str(g["room_scene"]))
+    rgb, _, _, draws = O.begin_render(sc.flat_bytes(), sc.width, sc.height)
+    assert draws == int(g["room_draws"])
+    assert np.array_equal(rgb, g["room_rgb8"])
+    fv = sc.flat_view().header.camera
+    cam = np.array(list(fv.top_left) + list(fv.dd_x) + list(fv.dd_y), np.float32)
+    assert same_bits(cam, g["room_camera"][:9])                               # Main.cpp:179-192
+    assert same_bits(np.float32(sc.flat_view().header.all_light_intensity), g["room_camera"][9])  # Main.cpp:116-123
+
+
+def test_whole_program_photon_map_build_and_frame_vs_the_reference_s_own(load_scene, golden, O):
+    """The -DUSE_PhotonMap build: the reference's own BuildCausticPhotonMap() (Main.cpp:342-386, 1,000,000 photons, its emission
+    loop, ScalePhotonPowers, PrepareForIrradianceEstimation, the .dat it writes) followed by its own BeginRender() pixel loop with
+    the k = 1000 gather in every Shade().  The oracle must arrive at the same 24 MB of photons, draw count and pixels."""
+    import hashlib
+    g = golden("begin_render")
+    sc = load_scene(str(g["caustic_scene"]))
+    n = int(g["caustic_photons"])
+    rgb, ph, emitted, draws = O.begin_render(sc.flat_bytes(), sc.width, sc.height, photon_budget=n)
+    assert len(ph) == n and draws == int(g["caustic_draws"]) and emitted > n
+    half = n // 2 - 1
+    ph[:, 19] &= np.where(np.arange(1, n + 1) < half, 0x0B, 0x08).astype(np.uint8)   # the bits the reference initialises
+    assert np.array_equal(ph[::997], g["caustic_photons_every_997"])
+    assert hashlib.sha256(np.ascontiguousarray(ph).tobytes()).hexdigest() == str(g["caustic_photons_sha"])
+    assert np.array_equal(rgb, g["caustic_rgb8"])
