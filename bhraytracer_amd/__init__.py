@@ -65,7 +65,7 @@ EXPORTS = [
     "bhrt_photon_get", "bhrt_photon_export", "bhrt_photon_import", "bhrt_photon_build_global", "bhrt_save_png", "bhrt_math_eval_dev",
     "bhrt_tiles_block_bytes", "bhrt_tiles_pack_dev", "bhrt_tiles_unpack_dev",
     "bhrt_first_hit", "bhrt_first_hit_dev", "bhrt_zbuffer_image_dev", "bhrt_color_image_dev",
-    "bhrt_scene_load_xml_ex", "bhrt_bvh_build", "bhrt_photon_emit_range", "bhrt_photon_install",
+    "bhrt_scene_load_xml_ex", "bhrt_bvh_build", "bhrt_photon_emit_range", "bhrt_photon_install", "bhrt_scene_clone", "bhrt_host_alloc", "bhrt_host_free",
 ]
 
 
@@ -258,6 +258,20 @@ class Scene:
         n = C.c_uint32(0)
         _check(lib().bhrt_photon_emit_range(self._h, C.byref(opts), int(bool(global_map)), C.c_uint64(e0), int(count), _ptr(out), int(capacity), C.byref(n)))
         return out[: n.value].copy()
+
+    def photon_emit_range_into(self, opts: Opts, e0: int, count: int, out_ptr: int, capacity: int, global_map: bool = False):
+        """Same, records written to `out_ptr` (host or device memory, room for `capacity` records).  Returns (n, ok): ok is False when
+        n > capacity (nothing usable was written; call again with room for n)."""
+        n = C.c_uint32(0)
+        rc = lib().bhrt_photon_emit_range(self._h, C.byref(opts), int(bool(global_map)), C.c_uint64(e0), int(count), C.c_void_p(out_ptr), int(capacity), C.byref(n))
+        if rc != 0 and n.value <= capacity:
+            _check(rc)
+        return n.value, rc == 0
+
+    def photon_install_ptr(self, ptr: int, n: int) -> int:
+        """Emission-order records at `ptr` (host or device memory) -> scaled, balanced and installed caustic map."""
+        _check(lib().bhrt_photon_install(self._h, C.c_void_p(ptr), int(n)))
+        return n
 
     def photon_install(self, records: np.ndarray) -> int:
         """Emission-order records (n, 24) -> scaled, balanced and installed caustic map."""

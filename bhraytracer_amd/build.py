@@ -55,7 +55,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
         _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lz", "-o", LIB])
     main_src = os.path.join(CSRC, "bhrt_main.cpp")
     if force or _newer([main_src, LIB] + headers, CLI):  # the C++ host program above the C ABI (Main.cpp:418-431)
-        _run(["g++"] + COMMON + ["-Wall", main_src, "-L" + HERE, "-lbhrt", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + "/opt/rocm/lib", "-o", CLI])
+        # host-only program (no device code): hipcc for the HIP runtime headers, linked against the C-ABI library and RCCL
+        _run([hipcc, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-result", main_src, "-L" + HERE, "-lbhrt", "-L/opt/rocm/lib", "-lrccl", "-lpthread",
+              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + "/opt/rocm/lib", "-o", CLI])
     return LIB
 
 

@@ -1,17 +1,32 @@
 // bhrt_main.cpp — C++ host program above the C ABI: the headless equivalent of the reference's main()
-// (Main.cpp:418-431: LoadScene -> ShowViewport -> BeginRender -> SaveImages), with the reference's compile-time
-// constants (scene path Main.cpp:423, output path Main.cpp:416, PT_SampleCount :141, GIBounceCount :130,
-// INTERNAL_REFLECTION_BOUNCE :41) as command-line options.
+// (Main.cpp:418-431: LoadScene -> ShowViewport -> BeginRender -> SaveImages; the seam viewport.cpp:425-449 calls BeginRender
+// synchronously), with the reference's compile-time constants (scene path Main.cpp:423, output path Main.cpp:416, PT_SampleCount
+// :141, GIBounceCount :130, INTERNAL_REFLECTION_BOUNCE :41) as command-line options.
 //
 //   bhrt render <scene.xml> [-o out.png] [--spp N] [--gi N] [--bounces N] [--seed S] [--no-jitter] [--no-gamma]
-//               [--device D] [--rank R --world N --tile T] [--radiance out.f32]
+//               [--device D | --gpus N] [--rank R --world N] [--tile T] [--radiance out.f32]
 //               [--photons N] [--photon-file map.dat] [--photon-out map.dat]     (USE_PhotonMap, Main.cpp:51,53,194,383)
 //   bhrt info   <scene.xml>
+//
+// --gpus N: ONE process drives N GPUs of the node (the reference's one process drives 16 OpenMP threads, Main.cpp:422): the
+// image is cut into interleaved tile x tile squares (tile t -> GPU t mod N), one host thread per GPU calls
+// bhrt_render_dev for its tiles, packs them (bhrt_tiles_pack_dev), ONE ncclAllGather over the RCCL communicator of the N devices
+// (xGMI) moves every GPU's block to all of them, bhrt_tiles_unpack_dev rebuilds the frame, GPU 0's copy is saved.  The caustic
+// photon map is emitted in disjoint emission-index ranges on the N GPUs (bhrt_photon_emit_range) and installed on every one
+// (bhrt_photon_install): the same map as on one GPU.  --gpus 1 runs the same code over a one-device communicator.
+// Without --gpus: one device, no RCCL involved (--rank / --world then render that rank's tiles only, for process-per-GPU launchers).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bhrt.h"
@@ -21,6 +36,133 @@ static int fail(const char *what)
     fprintf(stderr, "bhrt: %s: %s\n", what, bhrt_last_error());
     return 1;
 }
+#define HOST_CHECK(expr, what)                                                                  \
+    do {                                                                                        \
+        if ((expr) != 0) { fprintf(stderr, "bhrt: GPU %d: %s failed (%s)\n", r, what, #expr); \
+            failed.store(true); return; }                                                       \
+    } while (0)
+
+struct Args {
+    std::string scene, out = "out.png", radiance_out, photon_file, photon_out;
+    uint32_t photons = 0;
+    bhrt_opts o;
+    int device = 0, gpus = 0;
+};
+
+// BeginRender over N GPUs of this node; rgb / rad: the whole frame on the host (rad may be empty)
+static int render_multi(bhrt_scene *first, const Args &A, const bhrt_info &info, std::vector<uint8_t> &rgb, std::vector<float> &rad, std::vector<bhrt_stats> &stats,
+                        double &gather_seconds)
+{
+    const int N = A.gpus, W = info.width, H = info.height, tile = A.o.tile_size > 0 ? A.o.tile_size : 32;
+    int have = 0;
+    if (bhrt_device_count(&have) || have < N) { fprintf(stderr, "bhrt: --gpus %d but %d device(s) visible\n", N, have); return 1; }
+    std::vector<int> devs(N);
+    for (int r = 0; r < N; r++) devs[r] = r;
+    std::vector<ncclComm_t> comms(N);
+    if (ncclCommInitAll(comms.data(), N, devs.data()) != ncclSuccess) { fprintf(stderr, "bhrt: ncclCommInitAll over %d devices failed\n", N); return 1; }
+    std::vector<bhrt_scene *> scenes(N, nullptr);
+    scenes[0] = first;
+    for (int r = 1; r < N; r++)
+        if (bhrt_scene_clone(first, &scenes[r])) return fail("scene clone");
+    const size_t bb = bhrt_tiles_block_bytes(W, H, tile, N), npx = (size_t)W * H;
+    stats.assign(N, bhrt_stats());
+    std::atomic<bool> failed(false);
+
+    // ---- caustic photon map over the N GPUs (BuildCausticPhotonMap, Main.cpp:342-386): batches of emissions, GPU r takes the r-th
+    // slice of every batch, the host strings the slices together in emission order and every GPU installs the first `photons` records
+    if (!A.photon_file.empty()) {
+        for (int r = 0; r < N; r++)
+            if (bhrt_scene_upload(scenes[r], devs[r]) || bhrt_photon_import(scenes[r], A.photon_file.c_str(), 0)) return fail("photon import");
+    } else if (A.photons) {
+        const uint32_t per_rank = ((1u << 20) / (uint32_t)N) / 256 * 256;
+        std::vector<uint8_t> kept;
+        uint64_t e0 = 0, total = 0;
+        const uint64_t budget = (uint64_t)A.photons * 4096ull + (1ull << 24);
+        while (total < A.photons && e0 < budget) {
+            std::vector<std::vector<uint8_t>> part(N);
+            std::vector<uint32_t> cnt(N, 0);
+            std::vector<std::thread> th;
+            for (int r = 0; r < N; r++)
+                th.emplace_back([&, r]() {
+                    HOST_CHECK(bhrt_scene_upload(scenes[r], devs[r]), "upload");
+                    uint32_t cap = 4 * per_rank;
+                    for (int attempt = 0; attempt < 2; attempt++) { // "photons_out too small" reports the size it needs
+                        part[r].resize((size_t)cap * 24);
+                        if (bhrt_photon_emit_range(scenes[r], &A.o, 0, e0 + (uint64_t)r * per_rank, per_rank, part[r].data(), cap, &cnt[r]) == 0) return;
+                        if (cnt[r] <= cap) break;
+                        cap = cnt[r];
+                    }
+                    fprintf(stderr, "bhrt: GPU %d: photon emission: %s\n", r, bhrt_last_error());
+                    failed.store(true);
+                });
+            for (auto &t : th) t.join();
+            if (failed.load()) return 1;
+            for (int r = 0; r < N; r++) { kept.insert(kept.end(), part[r].begin(), part[r].begin() + (size_t)cnt[r] * 24); total += cnt[r]; }
+            e0 += (uint64_t)per_rank * N;
+        }
+        if (total == 0) { fprintf(stderr, "bhrt: photon map: no photon reached a photon surface\n"); return 1; }
+        const uint32_t n = (uint32_t)std::min<uint64_t>(total, A.photons);
+        for (int r = 0; r < N; r++)
+            if (bhrt_photon_install(scenes[r], kept.data(), n)) return fail("photon install");
+        printf("caustic photon map: %u photons from %llu emissions on %d GPU(s)\n", n, (unsigned long long)e0, N);
+    }
+    if ((A.o.photon_map || A.photons || !A.photon_file.empty()) && !A.photon_out.empty() && bhrt_photon_export(scenes[0], A.photon_out.c_str())) return fail("photon export");
+
+    // ---- the frame: one host thread per GPU.  The threads agree on failure at two rendezvous points (after set-up, after the render),
+    // so either all of them enter the collective or none does: a rank missing from an all-gather would hang the others.
+    std::vector<double> gather_s(N, 0.0);
+    std::atomic<int> ready(0), rendered(0);
+    auto rendezvous = [&](std::atomic<int> &c) { c.fetch_add(1); while (c.load() < N) std::this_thread::yield(); return !failed.load(); };
+    std::vector<std::thread> th;
+    for (int r = 0; r < N; r++)
+        th.emplace_back([&, r]() {
+            uint8_t *d_rgb = nullptr, *d_mine = nullptr, *d_all = nullptr;
+            float *d_rad = nullptr;
+            hipStream_t s = nullptr;
+            auto setup = [&]() {
+                HOST_CHECK(bhrt_scene_upload(scenes[r], devs[r]), "upload");
+                HOST_CHECK(hipSetDevice(devs[r]), "hipSetDevice");
+                HOST_CHECK(hipStreamCreate(&s), "stream");
+                HOST_CHECK(hipMalloc(&d_rgb, npx * 3), "hipMalloc");
+                HOST_CHECK(hipMalloc(&d_rad, npx * 3 * sizeof(float)), "hipMalloc");
+                HOST_CHECK(hipMalloc(&d_mine, bb), "hipMalloc");
+                HOST_CHECK(hipMalloc(&d_all, bb * N), "hipMalloc");
+                HOST_CHECK(hipMemsetAsync(d_rgb, 0, npx * 3, s), "memset");
+                HOST_CHECK(hipMemsetAsync(d_rad, 0, npx * 3 * sizeof(float), s), "memset");
+                HOST_CHECK(hipStreamSynchronize(s), "sync");
+            };
+            setup();
+            auto release = [&]() {
+                (void)hipFree(d_rgb); (void)hipFree(d_rad); (void)hipFree(d_mine); (void)hipFree(d_all);
+                if (s) (void)hipStreamDestroy(s);
+            };
+            if (!rendezvous(ready)) { release(); return; }
+            bhrt_opts o = A.o;
+            o.rank = r; o.world_size = N; o.tile_size = tile;
+            if (A.photons || !A.photon_file.empty()) o.photon_map = 1;
+            if (bhrt_render_dev(scenes[r], &o, d_rgb, d_rad, &stats[r], nullptr)) { fprintf(stderr, "bhrt: GPU %d: BeginRender: %s\n", r, bhrt_last_error()); failed.store(true); }
+            if (!rendezvous(rendered)) { release(); return; }
+            const auto t0 = std::chrono::steady_clock::now();
+            auto exchange = [&]() {
+                HOST_CHECK(bhrt_tiles_pack_dev(d_rgb, d_rad, W, H, tile, r, N, d_mine, s), "pack");
+                HOST_CHECK(ncclAllGather(d_mine, d_all, bb, ncclUint8, comms[r], s) != ncclSuccess, "ncclAllGather");
+                HOST_CHECK(bhrt_tiles_unpack_dev(d_all, W, H, tile, N, d_rgb, d_rad, s), "unpack");
+                HOST_CHECK(hipStreamSynchronize(s), "sync");
+                gather_s[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (r == 0) {
+                    HOST_CHECK(hipMemcpy(rgb.data(), d_rgb, npx * 3, hipMemcpyDeviceToHost), "copy");
+                    if (!rad.empty()) HOST_CHECK(hipMemcpy(rad.data(), d_rad, npx * 3 * sizeof(float), hipMemcpyDeviceToHost), "copy");
+                }
+            };
+            exchange();
+            release();
+        });
+    for (auto &t : th) t.join();
+    gather_seconds = *std::max_element(gather_s.begin(), gather_s.end());
+    for (int r = 0; r < N; r++) ncclCommDestroy(comms[r]);
+    for (int r = 1; r < N; r++) bhrt_scene_free(scenes[r]);
+    return failed.load() ? 1 : 0;
+}
 
 int main(int argc, char **argv)
 {
@@ -29,34 +171,34 @@ int main(int argc, char **argv)
         return 2;
     }
     const bool render = !strcmp(argv[1], "render");
-    const char *scene_path = argv[2];
-    std::string out = "out.png", radiance_out, photon_file, photon_out;
-    uint32_t photons = 0;
-    bhrt_opts o;
+    Args A;
+    A.scene = argv[2];
+    bhrt_opts &o = A.o;
     bhrt_default_opts(&o);
-    int device = 0;
     for (int a = 3; a < argc; a++) {
         std::string s = argv[a];
         auto next = [&]() -> const char * { if (a + 1 >= argc) { fprintf(stderr, "bhrt: %s needs a value\n", s.c_str()); exit(2); } return argv[++a]; };
-        if (s == "-o") out = next();
+        if (s == "-o") A.out = next();
         else if (s == "--spp") o.spp = atoi(next());
         else if (s == "--gi") o.gi_bounces = atoi(next());
         else if (s == "--bounces") o.internal_bounces = atoi(next());
         else if (s == "--seed") o.seed = (uint32_t)strtoul(next(), nullptr, 10);
         else if (s == "--no-jitter") o.jitter = 0;
         else if (s == "--no-gamma") o.gamma = 0;
-        else if (s == "--device") device = atoi(next());
+        else if (s == "--device") A.device = atoi(next());
+        else if (s == "--gpus") A.gpus = atoi(next());
         else if (s == "--rank") o.rank = atoi(next());
         else if (s == "--world") o.world_size = atoi(next());
         else if (s == "--tile") o.tile_size = atoi(next());
-        else if (s == "--radiance") radiance_out = next();
-        else if (s == "--photons") photons = (uint32_t)strtoul(next(), nullptr, 10);
-        else if (s == "--photon-file") photon_file = next();
-        else if (s == "--photon-out") photon_out = next();
+        else if (s == "--radiance") A.radiance_out = next();
+        else if (s == "--photons") A.photons = (uint32_t)strtoul(next(), nullptr, 10);
+        else if (s == "--photon-file") A.photon_file = next();
+        else if (s == "--photon-out") A.photon_out = next();
         else { fprintf(stderr, "bhrt: unknown option %s\n", s.c_str()); return 2; }
     }
+    if (A.gpus < 0 || A.gpus > 64 || (A.gpus > 0 && (o.rank != 0 || o.world_size != 1))) { fprintf(stderr, "bhrt: --gpus N drives all N ranks itself (no --rank / --world)\n"); return 2; }
     bhrt_scene *scene = nullptr;
-    if (bhrt_scene_load_xml(scene_path, &scene)) return fail("LoadScene");
+    if (bhrt_scene_load_xml(A.scene.c_str(), &scene)) return fail("LoadScene");
     bhrt_info info;
     bhrt_scene_info(scene, &info);
     for (uint32_t i = 0; i < info.n_warnings; i++) {
@@ -67,33 +209,52 @@ int main(int argc, char **argv)
     printf("nodes %u, meshes %u (%u triangles, %u BVH nodes), materials %u, lights %u, textures %u, scene blob %llu bytes\n", info.n_nodes,
            info.n_meshes, info.n_triangles, info.n_bvh_nodes, info.n_materials, info.n_lights, info.n_textures, (unsigned long long)info.flat_bytes);
     if (!render) { bhrt_scene_free(scene); return 0; }
-    if (bhrt_scene_upload(scene, device)) return fail("upload");
     std::vector<uint8_t> rgb((size_t)info.width * info.height * 3, 0);
-    std::vector<float> rad(radiance_out.empty() ? 0 : (size_t)info.width * info.height * 3, 0.f);
-    if (!photon_file.empty()) { // a cached photon pass
-        if (bhrt_photon_import(scene, photon_file.c_str(), 0)) return fail("photon import");
-        o.photon_map = 1;
-    } else if (photons) { // BuildCausticPhotonMap, Main.cpp:194
-        uint32_t stored = 0;
-        if (bhrt_photon_build(scene, &o, photons, &stored)) return fail("BuildCausticPhotonMap");
-        printf("caustic photon map: %u photons\n", stored);
-        o.photon_map = 1;
-    }
-    if (o.photon_map && !photon_out.empty() && bhrt_photon_export(scene, photon_out.c_str())) return fail("photon export");
+    std::vector<float> rad(A.radiance_out.empty() ? 0 : (size_t)info.width * info.height * 3, 0.f);
     bhrt_stats st;
-    if (bhrt_render(scene, &o, rgb.data(), rad.empty() ? nullptr : rad.data(), &st)) return fail("BeginRender");
+    memset(&st, 0, sizeof st);
+    if (A.gpus > 0) {
+        std::vector<bhrt_stats> per;
+        double gather_s = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (render_multi(scene, A, info, rgb, rad, per, gather_s)) return 1;
+        const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        double slowest = 0;
+        for (int r = 0; r < A.gpus; r++) {
+            st.closest_rays += per[r].closest_rays; st.shadow_rays += per[r].shadow_rays; st.camera_samples += per[r].camera_samples;
+            st.wave_iterations = std::max(st.wave_iterations, per[r].wave_iterations); st.passes = std::max(st.passes, per[r].passes);
+            slowest = std::max(slowest, per[r].seconds_total);
+            printf("GPU %d: %llu camera samples, %llu rays, %.3f s\n", r, (unsigned long long)per[r].camera_samples,
+                   (unsigned long long)(per[r].closest_rays + per[r].shadow_rays), per[r].seconds_total);
+        }
+        st.seconds_total = slowest;
+        printf("%d GPU(s): frame %.3f s on the slowest GPU, RCCL tile gather %.4f s, %.3f s wall incl. set-up\n", A.gpus, slowest, gather_s, wall);
+    } else {
+        if (bhrt_scene_upload(scene, A.device)) return fail("upload");
+        if (!A.photon_file.empty()) { // a cached photon pass
+            if (bhrt_photon_import(scene, A.photon_file.c_str(), 0)) return fail("photon import");
+            o.photon_map = 1;
+        } else if (A.photons) { // BuildCausticPhotonMap, Main.cpp:194
+            uint32_t stored = 0;
+            if (bhrt_photon_build(scene, &o, A.photons, &stored)) return fail("BuildCausticPhotonMap");
+            printf("caustic photon map: %u photons\n", stored);
+            o.photon_map = 1;
+        }
+        if (o.photon_map && !A.photon_out.empty() && bhrt_photon_export(scene, A.photon_out.c_str())) return fail("photon export");
+        if (bhrt_render(scene, &o, rgb.data(), rad.empty() ? nullptr : rad.data(), &st)) return fail("BeginRender");
+    }
     const double rays = (double)st.closest_rays + (double)st.shadow_rays;
     printf("rendered %llu camera samples, %.0f rays (%llu closest + %llu shadow), %u wave steps in %u pass(es): %.3f s, %.1f Mrays/s\n",
            (unsigned long long)st.camera_samples, rays, (unsigned long long)st.closest_rays, (unsigned long long)st.shadow_rays, st.wave_iterations,
            st.passes, st.seconds_total, rays / st.seconds_total / 1e6);
-    if (bhrt_save_png(out.c_str(), rgb.data(), info.width, info.height)) return fail("SaveImage");
-    if (!radiance_out.empty()) {
-        FILE *fp = fopen(radiance_out.c_str(), "wb");
-        if (!fp) { fprintf(stderr, "bhrt: cannot write %s\n", radiance_out.c_str()); return 1; }
+    if (bhrt_save_png(A.out.c_str(), rgb.data(), info.width, info.height)) return fail("SaveImage");
+    if (!A.radiance_out.empty()) {
+        FILE *fp = fopen(A.radiance_out.c_str(), "wb");
+        if (!fp) { fprintf(stderr, "bhrt: cannot write %s\n", A.radiance_out.c_str()); return 1; }
         fwrite(rad.data(), sizeof(float), rad.size(), fp);
         fclose(fp);
     }
-    printf("wrote %s\n", out.c_str());
+    printf("wrote %s\n", A.out.c_str());
     bhrt_scene_free(scene);
     return 0;
 }

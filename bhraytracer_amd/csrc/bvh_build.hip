@@ -441,6 +441,6 @@ int BuildBvhDevice(HostMesh &m, unsigned max_per, int device)
 
 extern "C" int bhrt_bvh_build(const float *vertices, uint32_t n_vertices, const uint32_t *faces, uint32_t n_faces, uint32_t max_per_leaf, int device,
                               struct bhrt_bvh_node *nodes_out, uint32_t node_capacity, uint32_t *n_nodes, uint32_t *elems_out, uint32_t *depth)
-{
+try {
     return bhrt::BuildBvhOnDevice(vertices, n_vertices, faces, n_faces, max_per_leaf, device, nodes_out, node_capacity, n_nodes, elems_out, depth);
-}
+} catch (...) { return bhrt::AbiException(); }

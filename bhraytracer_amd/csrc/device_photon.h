@@ -119,8 +119,7 @@ __device__ inline uint32_t emit_photon_path(const DevScene &S, uint32_t seed, ui
                                             float sum_intensity, DPhoton *out, uint32_t cap)
 {
     DRng g;
-    g.key = bhrt_photon_key(seed, emission);
-    g.ctr = 0;
+    bhrt_photon_stream(seed, emission, &g.key, &g.ctr);
     // light choice, Main.cpp:365-371
     float rnd = g.rnd01();
     int li = 0;

@@ -1378,6 +1378,13 @@ struct DeviceState {
     uint32_t *d_long = nullptr;  // queries whose walk outlasted the lane budget in pass 1
     uint32_t *d_cell_of = nullptr, *d_gorder = nullptr; // gather order (cell sort): heavy_cap entries each
     uint32_t *d_cells = nullptr, *d_tile_sums = nullptr;
+    // a capacity overflow halves the pass (RenderRange); later frames of the same scene and options start from the reduced size
+    uint64_t pass_hint_key = 0;
+    uint32_t pass_hint = 0;
+    // bhrt_render: the device copy of the frame, kept between calls
+    uint8_t *d_frame_rgb = nullptr;
+    float *d_frame_rad = nullptr;
+    size_t frame_px = 0;
     // scratch for the public trace API
     float *d_api_f = nullptr;
     int32_t *d_api_i = nullptr;
@@ -1392,6 +1399,7 @@ void DestroyDeviceState(DeviceState *d)
     fr(d->d_blob); fr(d->d_chain);
     for (int k = 0; k < 2; k++) { fr(d->d_rayf[k]); fr(d->d_rayu[k]); }
     fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_park); fr(d->d_seg); fr(d->d_cnt); fr(d->d_aux);
+    fr(d->d_frame_rgb); fr(d->d_frame_rad);
     fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_cells); fr(d->d_tile_sums);
     if (d->h_n_heavy) (void)hipHostFree(d->h_n_heavy);
     if (d->h_pub) (void)hipHostFree(d->h_pub);
@@ -1693,6 +1701,9 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
 
     uint64_t q = 0;
     uint32_t pass_limit = 0; // samples actually put in flight per pass (<= buffer capacity)
+    const uint64_t hint_key = ((uint64_t)(uint32_t)o.spp << 48) ^ ((uint64_t)(uint32_t)(o.gi_bounces + 1) << 40) ^ ((uint64_t)(uint32_t)o.internal_bounces << 32) ^
+                              ((uint64_t)(uint32_t)world << 24) ^ ((uint64_t)(uint32_t)tile << 8) ^ (uint64_t)(o.photon_map ? 1 : 0) ^ ((uint64_t)pass_samples << 1);
+    if (D->pass_hint_key == hint_key && D->pass_hint) pass_limit = D->pass_hint;
     while (q < owned_pixels) {
         int rc = EnsureWorkspace(D, pass_samples, frames_per_sample);
         if (rc) return rc;
@@ -1725,7 +1736,8 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         int cur = 0;
         std::vector<uint32_t> frame_marks = {0};
         bool overflow = false;
-        uint64_t pass_closest = 0;
+        uint64_t pass_closest = 0, pass_camera = 0, pass_shadow = 0;
+        uint32_t pass_steps = 0; // ray counters of this pass: added to *st only when the pass completes (an overflowing pass is redone)
         while (n_cur > 0) {
             {
                 Timer t(D, &st->seconds_trace_closest);
@@ -1785,23 +1797,25 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             if (first_step) { // camera step: dead rays of edge tiles are not rays
                 const uint64_t valid_px = CountValidPixels(P, npx);
                 pass_closest = valid_px * (uint64_t)o.spp;
-                st->camera_samples += pass_closest;
+                pass_camera = pass_closest;
                 first_step = false;
             } else pass_closest += n_cur;
             const uint32_t n_sh = hc.n_shadow;
-            if (n_sh) { st->shadow_rays += n_sh; st->launches_trace_shadow++; }
+            if (n_sh) { pass_shadow += n_sh; st->launches_trace_shadow++; }
             frame_marks.push_back(hc.n_frames);
             n_cur = hc.n_next;
             cur ^= 1;
-            st->wave_iterations++;
+            pass_steps++;
         }
         if (overflow) {
             // a capacity was exceeded: redo this pass with half the pixels in the same buffers
             // (results do not depend on the pass size: every sample has its own RNG key)
             if (pass_limit <= (uint32_t)o.spp) { SetError("wavefront buffers overflow even with one pixel per pass"); return BHRT_ERR_OVERFLOW; }
             pass_limit = std::max<uint32_t>((uint32_t)o.spp, pass_limit / 2);
+            D->pass_hint_key = hint_key; D->pass_hint = pass_limit;
             continue;
         }
+        st->camera_samples += pass_camera; st->shadow_rays += pass_shadow; st->wave_iterations += pass_steps;
         if (o.photon_map && frame_marks.back() > 0) {
             // caustic term (MtlBlinn.cpp:329-342) of every frame of the pass in ONE gather: a gather launch lasts as long as its
             // longest query (15-80 ms for a query that fills the 1000-candidate heap), so a gather per wave step — 23 steps
@@ -1842,17 +1856,17 @@ using namespace bhrt;
 extern "C" {
 
 int bhrt_device_count(int *n)
-{
+try {
     if (!n) { SetError("null argument"); return BHRT_ERR_ARG; }
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
     if (e != hipSuccess) { *n = 0; SetError(std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); return BHRT_ERR_NO_DEVICE; }
     *n = c;
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_scene_upload(bhrt_scene *scene, int device)
-{
+try {
     if (!scene) { SetError("null scene"); return BHRT_ERR_ARG; }
     if (scene->dev && scene->dev->device == device) { HIP_CHECK(hipSetDevice(device)); return BHRT_OK; }
     int count = 0;
@@ -1935,7 +1949,7 @@ int bhrt_scene_upload(bhrt_scene *scene, int device)
         S.tapy[i] = r * dm::cosf_(y * (float)M_PI * 2);
     }
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 static int EnsureApiScratch(DeviceState *D, size_t n)
 {
@@ -1950,7 +1964,7 @@ static int EnsureApiScratch(DeviceState *D, size_t n)
 }
 
 int bhrt_trace_closest_dev(bhrt_scene *scene, const float *d_rays_soa, int hit_side, size_t n, bhrt_hits d_out, void *stream)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     if (!d_rays_soa || !d_out.t || !d_out.node || !d_out.prim || !d_out.front) { SetError("null buffer"); return BHRT_ERR_ARG; }
@@ -1967,10 +1981,10 @@ int bhrt_trace_closest_dev(bhrt_scene *scene, const float *d_rays_soa, int hit_s
     HIP_CHECK(hipGetLastError());
     if (!stream) HIP_CHECK(hipStreamSynchronize(s));
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_trace_closest_host(bhrt_scene *scene, const float *rays_soa, int hit_side, size_t n, bhrt_hits out)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     if (n == 0) return BHRT_OK;
@@ -1987,10 +2001,10 @@ int bhrt_trace_closest_host(bhrt_scene *scene, const float *rays_soa, int hit_si
     HIP_CHECK(hipMemcpy(out.prim, d.prim, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(out.front, d.front, n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_trace_shadow_dev(bhrt_scene *scene, const float *d_rays_soa, const float *d_tmax, size_t n, float *d_vis, void *stream)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     if (!d_rays_soa || !d_tmax || !d_vis) { SetError("null buffer"); return BHRT_ERR_ARG; }
@@ -2007,10 +2021,10 @@ int bhrt_trace_shadow_dev(bhrt_scene *scene, const float *d_rays_soa, const floa
     HIP_CHECK(hipGetLastError());
     if (!stream) HIP_CHECK(hipStreamSynchronize(s));
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_trace_shadow_host(bhrt_scene *scene, const float *rays_soa, const float *tmax, size_t n, float *vis)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     if (n == 0) return BHRT_OK;
@@ -2024,10 +2038,10 @@ int bhrt_trace_shadow_host(bhrt_scene *scene, const float *rays_soa, const float
     if (rc) return rc;
     HIP_CHECK(hipMemcpy(vis, D->d_api_f + 7 * n, n * sizeof(float), hipMemcpyDeviceToHost));
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_render_dev(bhrt_scene *scene, const bhrt_opts *opts, uint8_t *d_rgb8, float *d_radiance, bhrt_stats *stats, void *stream)
-{
+try {
     (void)stream; // the render pipeline synchronises its own stream per wave step
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
@@ -2038,30 +2052,55 @@ int bhrt_render_dev(bhrt_scene *scene, const bhrt_opts *opts, uint8_t *d_rgb8, f
     rc = RenderRange(scene, *opts, d_rgb8, d_radiance, &local, nullptr, 0, 0, 0, 0);
     if (stats) *stats = local;
     return rc;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_render(bhrt_scene *scene, const bhrt_opts *opts, uint8_t *rgb8, float *radiance, bhrt_stats *stats)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
+    if (!opts) { SetError("null opts"); return BHRT_ERR_ARG; }
+    DeviceState *D = scene->dev;
     const bhrt_flat_header *H = scene->flat.hdr();
     const size_t npix = (size_t)H->camera.width * H->camera.height;
-    uint8_t *d_rgb = nullptr;
-    float *d_rad = nullptr;
-    if (rgb8) { HIP_CHECK(hipMalloc(&d_rgb, npix * 3)); HIP_CHECK(hipMemcpy(d_rgb, rgb8, npix * 3, hipMemcpyHostToDevice)); }
-    if (radiance) { HIP_CHECK(hipMalloc(&d_rad, npix * 3 * sizeof(float))); HIP_CHECK(hipMemcpy(d_rad, radiance, npix * 3 * sizeof(float), hipMemcpyHostToDevice)); }
-    rc = bhrt_render_dev(scene, opts, d_rgb, d_rad, stats, nullptr);
-    if (rc == BHRT_OK) {
-        if (rgb8) HIP_CHECK(hipMemcpy(rgb8, d_rgb, npix * 3, hipMemcpyDeviceToHost));
-        if (radiance) HIP_CHECK(hipMemcpy(radiance, d_rad, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    // The frame lives in HBM between calls (no allocation per frame).  The copies run at the full PCIe rate when the caller's
+    // buffers are pinned (bhrt_host_alloc); pageable buffers work at about half of it.
+    if (D->frame_px < npix) {
+        if (D->d_frame_rgb) (void)hipFree(D->d_frame_rgb);
+        if (D->d_frame_rad) (void)hipFree(D->d_frame_rad);
+        D->d_frame_rgb = nullptr; D->d_frame_rad = nullptr; D->frame_px = 0;
+        HIP_CHECK(hipMalloc(&D->d_frame_rgb, npix * 3));
+        HIP_CHECK(hipMalloc(&D->d_frame_rad, npix * 3 * sizeof(float)));
+        D->frame_px = npix;
     }
-    if (d_rgb) (void)hipFree(d_rgb);
-    if (d_rad) (void)hipFree(d_rad);
-    return rc;
+    if (opts->world_size > 1) { // pixels of tiles owned by other ranks keep the caller's values: they have to be in the device copy first
+        if (rgb8) HIP_CHECK(hipMemcpyAsync(D->d_frame_rgb, rgb8, npix * 3, hipMemcpyHostToDevice, D->stream));
+        if (radiance) HIP_CHECK(hipMemcpyAsync(D->d_frame_rad, radiance, npix * 12, hipMemcpyHostToDevice, D->stream));
+    }
+    rc = bhrt_render_dev(scene, opts, rgb8 ? D->d_frame_rgb : nullptr, radiance ? D->d_frame_rad : nullptr, stats, nullptr);
+    if (rc) return rc;
+    if (rgb8) HIP_CHECK(hipMemcpyAsync(rgb8, D->d_frame_rgb, npix * 3, hipMemcpyDeviceToHost, D->stream));
+    if (radiance) HIP_CHECK(hipMemcpyAsync(radiance, D->d_frame_rad, npix * 12, hipMemcpyDeviceToHost, D->stream));
+    HIP_CHECK(hipStreamSynchronize(D->stream));
+    return BHRT_OK;
+} catch (...) { return bhrt::AbiException(); }
+
+// pinned host memory for frame buffers handed to bhrt_render (and anything else that crosses PCIe)
+int bhrt_host_alloc(void **ptr, size_t bytes)
+try {
+    if (!ptr || bytes == 0) { SetError("bhrt_host_alloc: bad argument"); return BHRT_ERR_ARG; }
+    *ptr = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { SetError("no HIP device available"); return BHRT_ERR_NO_DEVICE; }
+    HIP_CHECK(hipHostMalloc(ptr, bytes));
+    return BHRT_OK;
+} catch (...) { return bhrt::AbiException(); }
+void bhrt_host_free(void *ptr)
+{
+    if (ptr) (void)hipHostFree(ptr);
 }
 
 int bhrt_render_samples(bhrt_scene *scene, const bhrt_opts *opts, int x0, int y0, int x1, int y1, float *samples, bhrt_stats *stats)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     if (!opts || !samples) { SetError("null argument"); return BHRT_ERR_ARG; }
@@ -2079,11 +2118,11 @@ int bhrt_render_samples(bhrt_scene *scene, const bhrt_opts *opts, int x0, int y0
     (void)hipFree(d_s);
     if (stats) *stats = local;
     return rc;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 // ---- images beside the colour image ---------------------------------------------------------------
 int bhrt_first_hit_dev(bhrt_scene *scene, float *d_z, float *d_normal, float *d_albedo, void *stream)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     DeviceState *D = scene->dev;
@@ -2095,10 +2134,10 @@ int bhrt_first_hit_dev(bhrt_scene *scene, float *d_z, float *d_normal, float *d_
     HIP_CHECK(hipGetLastError());
     if (!stream) HIP_CHECK(hipStreamSynchronize(st));
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_first_hit(bhrt_scene *scene, float *z, float *normal, float *albedo)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     DeviceState *D = scene->dev;
@@ -2116,10 +2155,10 @@ int bhrt_first_hit(bhrt_scene *scene, float *z, float *normal, float *albedo)
     if (rc) return rc;
     HIP_CHECK(e);
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_zbuffer_image_dev(bhrt_scene *scene, const float *d_z, size_t n, uint8_t *d_img, void *stream)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     if (!d_z || !d_img || n == 0 || n > 0xffffffffull) { SetError("bad z-buffer arguments"); return BHRT_ERR_ARG; }
@@ -2132,10 +2171,10 @@ int bhrt_zbuffer_image_dev(bhrt_scene *scene, const float *d_z, size_t n, uint8_
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(st)); // the range scratch is shared with the other API calls
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_color_image_dev(bhrt_scene *scene, const float *d_radiance, size_t n_pixels, int gamma, float *d_color, void *stream)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     if (!d_radiance || !d_color || n_pixels * 3 > 0xffffffffull) { SetError("bad colour image arguments"); return BHRT_ERR_ARG; }
@@ -2145,7 +2184,7 @@ int bhrt_color_image_dev(bhrt_scene *scene, const float *d_radiance, size_t n_pi
     HIP_CHECK(hipGetLastError());
     if (!stream) HIP_CHECK(hipStreamSynchronize(st));
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 static bool TileArgsOk(int W, int H, int tile, int rank, int world)
 {
@@ -2165,7 +2204,7 @@ static uint32_t TilesPixelsPerRank(int width, int height, int tile, int world)
     return (uint32_t)(((n_tiles + (size_t)world - 1) / (size_t)world) * (size_t)tile * tile);
 }
 int bhrt_tiles_pack_dev(const uint8_t *d_rgb8, const float *d_radiance, int width, int height, int tile, int rank, int world, void *d_block, void *stream)
-{
+try {
     if (!TileArgsOk(width, height, tile, rank, world)) return BHRT_ERR_ARG;
     if (!d_rgb8 || !d_radiance || !d_block) { SetError("null buffer"); return BHRT_ERR_ARG; }
     const uint32_t px = TilesPixelsPerRank(width, height, tile, world);
@@ -2173,9 +2212,9 @@ int bhrt_tiles_pack_dev(const uint8_t *d_rgb8, const float *d_radiance, int widt
                        (width + tile - 1) / tile, rank, world, px, (float *)d_block, (uint8_t *)d_block + (size_t)px * 12);
     HIP_CHECK(hipGetLastError());
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 int bhrt_tiles_unpack_dev(const void *d_blocks, int width, int height, int tile, int world, uint8_t *d_rgb8, float *d_radiance, void *stream)
-{
+try {
     if (!TileArgsOk(width, height, tile, 0, world)) return BHRT_ERR_ARG;
     if (!d_rgb8 || !d_radiance || !d_blocks) { SetError("null buffer"); return BHRT_ERR_ARG; }
     const size_t bb = bhrt_tiles_block_bytes(width, height, tile, world);
@@ -2185,10 +2224,10 @@ int bhrt_tiles_unpack_dev(const void *d_blocks, int width, int height, int tile,
                        height, tile, (width + tile - 1) / tile, world, px, d_rgb8, d_radiance);
     HIP_CHECK(hipGetLastError());
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_math_eval_dev(int fn, const float *a, const float *b, size_t n, float *out)
-{
+try {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { SetError("no HIP device available"); return BHRT_ERR_NO_DEVICE; }
     if (!a || !out || fn < 0 || fn > 9) { SetError("bad argument"); return BHRT_ERR_ARG; }
@@ -2202,7 +2241,7 @@ int bhrt_math_eval_dev(int fn, const float *a, const float *b, size_t n, float *
     HIP_CHECK(hipMemcpy(out, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost));
     (void)hipFree(d);
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 // D->h_photons (balanced, heap order, slot 0 unused) -> HBM: the 24-byte records, the decoded hot/cold copy the gather
 // walks (PhotonMapDev) and the bounds of the photon positions.
@@ -2250,10 +2289,13 @@ static int BuildPhotons(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_p
     float sum = 0;
     for (int32_t i : pl) sum += key(i);
 
-    DPhoton *d_out = nullptr, *d_tmp = nullptr;
-    uint32_t *d_counts = nullptr, *d_offsets = nullptr;
-    int32_t *d_pl = nullptr;
-    auto cleanup = [&]() { if (d_tmp) (void)hipFree(d_tmp); if (d_counts) (void)hipFree(d_counts); if (d_offsets) (void)hipFree(d_offsets); if (d_pl) (void)hipFree(d_pl); };
+    struct Bufs { // freed on every return path, HIP_CHECK's included
+        DPhoton *out = nullptr, *tmp = nullptr; uint32_t *counts = nullptr, *offsets = nullptr; int32_t *pl = nullptr;
+        ~Bufs() { (void)hipFree(out); (void)hipFree(tmp); (void)hipFree(counts); (void)hipFree(offsets); (void)hipFree(pl); }
+    } bufs;
+    DPhoton *&d_out = bufs.out, *&d_tmp = bufs.tmp;
+    uint32_t *&d_counts = bufs.counts, *&d_offsets = bufs.offsets;
+    int32_t *&d_pl = bufs.pl;
     HIP_CHECK(hipMalloc(&d_out, ((size_t)max_photons + 1) * sizeof(DPhoton)));
     HIP_CHECK(hipMemset(d_out, 0, ((size_t)max_photons + 1) * sizeof(DPhoton)));
     const uint32_t E = global_map ? 1u << 16 : 1u << 20; // emissions per batch (nearly every emission of the global map stores photons)
@@ -2288,15 +2330,13 @@ static int BuildPhotons(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_p
         stored = run;
         e0 += E;
     }
-    cleanup();
     const uint32_t n = (uint32_t)std::min<uint64_t>(stored, max_photons);
-    if (n == 0) { (void)hipFree(d_out); SetError("photon map: no photon reached a photon surface"); return BHRT_ERR_UNSUPPORTED; }
+    if (n == 0) { SetError("photon map: no photon reached a photon surface"); return BHRT_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_photon_scale, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, d_out, n, 1.f / (float)(int)n); // Main.cpp:380
     // PrepareForIrradianceEstimation on the host (cyPhotonMap.h:236-258), then back to HBM
     out.assign((size_t)n + 1, HostPhoton());
     HIP_CHECK(hipMemcpyAsync(out.data(), d_out, ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyDeviceToHost, D->stream));
     HIP_CHECK(hipStreamSynchronize(D->stream));
-    (void)hipFree(d_out);
     memset(&out[0], 0, sizeof(HostPhoton));
     BalancePhotons(out);
     return BHRT_OK;
@@ -2307,7 +2347,7 @@ static int BuildPhotons(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_p
 // same map: the first max_photons records in emission order, exactly what bhrt_photon_build keeps.
 int bhrt_photon_emit_range(bhrt_scene *scene, const bhrt_opts *opts, int global_map, uint64_t e0, uint32_t count, void *photons_out, uint32_t capacity,
                            uint32_t *n_photons)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     if (!opts || !photons_out || !n_photons || count == 0 || count % kBlock != 0 || count > (1u << 24)) { SetError("photon emit range: bad arguments (count must be a multiple of 256)"); return BHRT_ERR_ARG; }
@@ -2352,14 +2392,14 @@ int bhrt_photon_emit_range(bhrt_scene *scene, const bhrt_opts *opts, int global_
     HIP_CHECK(hipMalloc(&b.out, ((size_t)total + 1) * sizeof(DPhoton)));
     HIP_CHECK(hipMemcpyAsync(b.offsets, offsets.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, D->stream));
     hipLaunchKernelGGL(k_photon_compact, dim3(count / kBlock), dim3(kBlock), 0, D->stream, b.tmp, cap, b.counts, b.offsets, count, (uint32_t)total, b.out);
-    HIP_CHECK(hipMemcpyAsync(photons_out, b.out + 1, (size_t)total * sizeof(DPhoton), hipMemcpyDeviceToHost, D->stream));
+    HIP_CHECK(hipMemcpyAsync(photons_out, b.out + 1, (size_t)total * sizeof(DPhoton), hipMemcpyDefault, D->stream)); // host or device destination
     HIP_CHECK(hipStreamSynchronize(D->stream));
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 // n records in emission order with unscaled power -> ScalePhotonPowers(1 / n) (Main.cpp:380), balance, install for the gather
 int bhrt_photon_install(bhrt_scene *scene, const void *records, uint32_t n)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     if (!records || n == 0 || n > (1u << 28)) { SetError("photon install: bad arguments"); return BHRT_ERR_ARG; }
@@ -2367,7 +2407,7 @@ int bhrt_photon_install(bhrt_scene *scene, const void *records, uint32_t n)
     DPhoton *d = nullptr;
     HIP_CHECK(hipMalloc(&d, ((size_t)n + 1) * sizeof(DPhoton)));
     hipError_t e = hipMemset(d, 0, sizeof(DPhoton));
-    if (e == hipSuccess) e = hipMemcpy(d + 1, records, (size_t)n * sizeof(DPhoton), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 1, records, (size_t)n * sizeof(DPhoton), hipMemcpyDefault); // host or device source
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_photon_scale, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, d, n, 1.f / (float)(int)n);
         D->h_photons.assign((size_t)n + 1, HostPhoton());
@@ -2379,10 +2419,10 @@ int bhrt_photon_install(bhrt_scene *scene, const void *records, uint32_t n)
     memset(&D->h_photons[0], 0, sizeof(HostPhoton));
     BalancePhotons(D->h_photons);
     return InstallPhotonMap(D);
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, uint32_t *n_stored)
-{
+try {
     if (!scene) { SetError("null scene"); return BHRT_ERR_ARG; }
     std::vector<HostPhoton> balanced;
     int rc = BuildPhotons(scene, opts, max_photons, false, balanced);
@@ -2393,11 +2433,11 @@ int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_pho
     if (rc) return rc;
     if (n_stored) *n_stored = D->n_photons;
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_photon_build_global(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, void *photons_out, uint32_t capacity, uint32_t *n_stored,
                              const char *dat_path)
-{
+try {
     if (!scene) { SetError("null scene"); return BHRT_ERR_ARG; }
     std::vector<HostPhoton> balanced;
     int rc = BuildPhotons(scene, opts, max_photons, true, balanced);
@@ -2416,11 +2456,11 @@ int bhrt_photon_build_global(bhrt_scene *scene, const bhrt_opts *opts, uint32_t 
         if (!ok) { SetError("short write"); return BHRT_ERR_IO; }
     }
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 
 int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *nrm, size_t cnt, float radius, float *irrad, float *dir)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     DeviceState *D = scene->dev;
@@ -2444,10 +2484,10 @@ int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *nrm,
     }
     (void)hipFree(d_buf);
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_photon_get(const bhrt_scene *scene, void *photons_out, uint32_t capacity, uint32_t *n)
-{
+try {
     if (!scene || !scene->dev || scene->dev->h_photons.empty()) { SetError("photon map: nothing built"); return BHRT_ERR_ARG; }
     const uint32_t have = scene->dev->n_photons;
     if (n) *n = have;
@@ -2456,10 +2496,10 @@ int bhrt_photon_get(const bhrt_scene *scene, void *photons_out, uint32_t capacit
         memcpy(photons_out, &scene->dev->h_photons[1], (size_t)have * sizeof(HostPhoton));
     }
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_photon_export(const bhrt_scene *scene, const char *dat_path)
-{
+try {
     if (!scene || !scene->dev || scene->dev->h_photons.empty() || !dat_path) { SetError("photon map: nothing to export"); return BHRT_ERR_ARG; }
     FILE *fp = fopen(dat_path, "wb"); // fwrite(GetPhotons(), sizeof(Photon), NumPhotons(), fp), Main.cpp:383-385
     if (!fp) { SetError(std::string("cannot write ") + dat_path); return BHRT_ERR_IO; }
@@ -2468,10 +2508,10 @@ int bhrt_photon_export(const bhrt_scene *scene, const char *dat_path)
     fclose(fp);
     if (!ok) { SetError("short write"); return BHRT_ERR_IO; }
     return BHRT_OK;
-}
+} catch (...) { return bhrt::AbiException(); }
 
 int bhrt_photon_import(bhrt_scene *scene, const char *dat_path, int rebalance)
-{
+try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     if (!dat_path) { SetError("null path"); return BHRT_ERR_ARG; }
@@ -2494,6 +2534,6 @@ int bhrt_photon_import(bhrt_scene *scene, const char *dat_path, int rebalance)
     memset(&D->h_photons[0], 0, sizeof(HostPhoton));
     if (rebalance) BalancePhotons(D->h_photons); // InitializePhotonMapByFile runs PrepareForIrradianceEstimation again (cyPhotonMap.h:409-417)
     return InstallPhotonMap(D);
-}
+} catch (...) { return bhrt::AbiException(); }
 
 } // extern "C"

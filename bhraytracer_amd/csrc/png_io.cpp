@@ -1,4 +1,4 @@
-// png_io.cpp — 8-bit PNG writer / reader on top of zlib.
+// png_io.cpp — 8-bit PNG writer and a PNG reader (every colour type and bit depth, not interlaced) on top of zlib.
 // Replaces the vendored lodepng the reference calls at Scenes/scene.h:634-644
 // (lodepng::encode, LCT_RGB / LCT_GREY, 8 bit) and Textures/Texture.cpp:76
 // (lodepng::decode to LCT_RGB).  Pixel bytes are what matters for parity, not the
@@ -87,10 +87,16 @@ bool LoadPngRgb(const char *path, std::vector<uint8_t> &rgb, int &w, int &h)
         else if (!memcmp(type, "IEND", 4)) break;
         p += 12 + len;
     }
-    if (w <= 0 || h <= 0 || bitdepth != 8 || interlace != 0) return false; // 8-bit, non-interlaced only
-    int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    // every colour type and bit depth of the PNG specification, as lodepng::decode(..., LCT_RGB, 8) (Texture.cpp:76) accepts them;
+    // Adam7-interlaced files are not read (the caller warns like for any texture that fails to load)
+    if (w <= 0 || h <= 0 || w > 32768 || h > 32768 || (size_t)w * h > ((size_t)1 << 28) || interlace != 0) return false;
+    const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch) return false;
-    size_t stride = (size_t)w * ch;
+    const bool depth_ok = ctype == 0 ? (bitdepth == 1 || bitdepth == 2 || bitdepth == 4 || bitdepth == 8 || bitdepth == 16)
+                        : ctype == 3 ? (bitdepth == 1 || bitdepth == 2 || bitdepth == 4 || bitdepth == 8) : (bitdepth == 8 || bitdepth == 16);
+    if (!depth_ok) return false;
+    const size_t bits_px = (size_t)ch * bitdepth, bpp = bits_px >= 8 ? bits_px / 8 : 1; // filter distance in bytes
+    const size_t stride = ((size_t)w * bits_px + 7) / 8;
     std::vector<uint8_t> raw((stride + 1) * h);
     uLongf rl = (uLongf)raw.size();
     if (uncompress(raw.data(), &rl, idat.data(), (uLong)idat.size()) != Z_OK || rl != raw.size()) return false;
@@ -102,9 +108,9 @@ bool LoadPngRgb(const char *path, std::vector<uint8_t> &rgb, int &w, int &h)
         uint8_t *out = &img[stride * y];
         const uint8_t *up = y ? &img[stride * (y - 1)] : nullptr;
         for (size_t x = 0; x < stride; x++) {
-            int a = x >= (size_t)ch ? out[x - ch] : 0;
+            int a = x >= bpp ? out[x - bpp] : 0;
             int b = up ? up[x] : 0;
-            int c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
+            int c = (up && x >= bpp) ? up[x - bpp] : 0;
             int v = in[x];
             switch (f) {
             case 0: break;
@@ -118,17 +124,28 @@ bool LoadPngRgb(const char *path, std::vector<uint8_t> &rgb, int &w, int &h)
         }
     }
     rgb.resize((size_t)w * h * 3);
-    for (size_t i = 0; i < (size_t)w * h; i++) {
-        const uint8_t *s = &img[i * ch];
-        uint8_t *o = &rgb[i * 3];
-        switch (ctype) {
-        case 0: case 4: o[0] = o[1] = o[2] = s[0]; break;
-        case 2: case 6: o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; break;
-        case 3: {
-            size_t k = (size_t)s[0] * 3;
-            if (k + 2 < plte.size()) { o[0] = plte[k]; o[1] = plte[k + 1]; o[2] = plte[k + 2]; }
-            else o[0] = o[1] = o[2] = 0;
-        } break;
+    // sample k of row y as an 8-bit value: 16-bit samples keep their high byte, samples below 8 bits are scaled to 0..255
+    // (grey) or kept as palette indices — the conversions lodepng applies
+    auto sample = [&](const uint8_t *row, size_t k, bool scale) -> unsigned {
+        if (bitdepth == 8) return row[k];
+        if (bitdepth == 16) return row[2 * k];
+        const size_t bit = k * bitdepth;
+        const unsigned v = (row[bit >> 3] >> (8 - bitdepth - (bit & 7))) & ((1u << bitdepth) - 1u);
+        return scale ? v * 255u / ((1u << bitdepth) - 1u) : v;
+    };
+    for (int y = 0; y < h; y++) {
+        const uint8_t *row = &img[stride * y];
+        for (int x = 0; x < w; x++) {
+            uint8_t *o = &rgb[((size_t)y * w + x) * 3];
+            switch (ctype) {
+            case 0: case 4: o[0] = o[1] = o[2] = (uint8_t)sample(row, (size_t)x * ch, true); break;
+            case 2: case 6: o[0] = (uint8_t)sample(row, (size_t)x * ch, true); o[1] = (uint8_t)sample(row, (size_t)x * ch + 1, true); o[2] = (uint8_t)sample(row, (size_t)x * ch + 2, true); break;
+            case 3: {
+                const size_t k = (size_t)sample(row, (size_t)x, false) * 3;
+                if (k + 2 < plte.size()) { o[0] = plte[k]; o[1] = plte[k + 1]; o[2] = plte[k + 2]; }
+                else o[0] = o[1] = o[2] = 0;
+            } break;
+            }
         }
     }
     return true;

@@ -291,7 +291,7 @@ struct Loader {
         if (buf[0] != 'P' && buf[1] != '6') { fclose(fp); return false; }
         readLine(buf, 1024);
         while (buf[0] == '#') readLine(buf, 1024);
-        if (sscanf(buf, "%d %d", &t.w, &t.h) != 2 || t.w <= 0 || t.h <= 0) { fclose(fp); return false; }
+        if (sscanf(buf, "%d %d", &t.w, &t.h) != 2 || t.w <= 0 || t.h <= 0 || t.w > 32768 || t.h > 32768 || (size_t)t.w * t.h > ((size_t)1 << 28)) { fclose(fp); return false; }
         readLine(buf, 1024);
         while (buf[0] == '#') readLine(buf, 1024);
         t.rgb.resize((size_t)t.w * t.h * 3);

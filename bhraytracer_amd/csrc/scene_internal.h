@@ -10,6 +10,9 @@
 namespace bhrt {
 struct DeviceState; // device_state.h (HIP side)
 void SetError(const std::string &msg);
+// No C++ exception crosses the C ABI: every `int bhrt_*` entry point is a function-try-block that ends in this handler
+// (std::bad_alloc from a file-sized allocation, std::length_error, ...): sets bhrt_last_error() and returns an error code.
+int AbiException();
 void DestroyDeviceState(DeviceState *d); // defined in the HIP TU
 } // namespace bhrt
 

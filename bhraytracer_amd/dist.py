@@ -89,37 +89,57 @@ def gather_framebuffer(img: torch.Tensor, tile: int, rank: int, world: int, grou
 
 def photon_build_sharded(scene, opts, max_photons: int, rank: int, world: int, group=None, batch: int = 1 << 20, device=None) -> int:
     """BuildCausticPhotonMap over `world` GPUs.  Emission is keyed by the emission index: per batch of `batch`
-    emissions rank r runs the r-th slice on its GPU (bhrt_photon_emit_range), ONE all_gather moves the slices' records to
-    everybody, and every rank keeps the first max_photons records in emission order and installs the same map
-    (bhrt_photon_install) — byte for byte the map bhrt_photon_build makes on one GPU."""
-    import numpy as np
+    emissions (2^20, the batch of the single-GPU build, so both stop after the same number of emissions when a scene runs out of
+    its emission budget) rank r runs the r-th slice on its GPU (bhrt_photon_emit_range), ONE all_gather moves the slices' records
+    to everybody, and every rank keeps the first max_photons records in emission order and installs the same map
+    (bhrt_photon_install) — byte for byte the map bhrt_photon_build makes on one GPU.
+    `device`: where the exchange buffers live.  A GPU (backend "nccl" = RCCL): the records go from the emission kernel's output
+    through the all_gather into the install without touching the host.  None: host memory (gloo).
+    A failure on one rank (HIP error, ...) is carried in the size exchange, so every rank raises instead of waiting forever."""
     import torch.distributed as dist
-    per_rank = (batch // world) // 256 * 256
-    assert per_rank > 0
+    blocks = batch // 256
+    assert blocks >= world and batch % 256 == 0
+    lo, hi = 256 * (blocks * rank // world), 256 * (blocks * (rank + 1) // world)  # this rank's slice of every batch
+    cap = max(4 * (hi - lo), 4096)
+    mine = torch.empty((cap, 24), dtype=torch.uint8, device=device)
     kept, total, e0 = [], 0, 0
     budget = max_photons * 4096 + (1 << 24)  # like BuildPhotons: a scene without a caustic path ends here
     while total < max_photons and e0 < budget:
-        mine = scene.photon_emit_range(opts, e0 + rank * per_rank, per_rank)
+        n, err = 0, None
+        try:
+            n, ok = scene.photon_emit_range_into(opts, e0 + lo, hi - lo, mine.data_ptr(), cap)
+            if not ok:  # more photons than there was room for: once more with room for all
+                cap = n
+                mine = torch.empty((cap, 24), dtype=torch.uint8, device=device)
+                n, ok = scene.photon_emit_range_into(opts, e0 + lo, hi - lo, mine.data_ptr(), cap)
+                assert ok
+        except Exception as e:  # noqa: BLE001 — reported to every rank below
+            n, err = -1, e
         if world == 1:
-            blocks = [mine]
+            if err is not None:
+                raise err
+            blocks_now = [mine[:n].clone()]
         else:
-            # `device`: where the exchange buffers live — the GPU for RCCL ("nccl"), None = host memory for gloo
             sizes = torch.zeros(world, dtype=torch.int64, device=device)
-            sizes[rank] = len(mine)
+            sizes[rank] = n
             dist.all_reduce(sizes, group=group)
             sizes = sizes.cpu()
+            if int(sizes.min()) < 0:
+                bad = [r for r in range(world) if int(sizes[r]) < 0]
+                raise RuntimeError(f"photon emission failed on rank(s) {bad}" + (f": {err}" if err is not None else ""))
             width = max(int(sizes.max()), 1)
             buf = torch.zeros((width, 24), dtype=torch.uint8, device=device)
-            buf[: len(mine)] = torch.from_numpy(mine).to(buf.device)
-            allb = torch.zeros((world * width, 24), dtype=torch.uint8, device=device)
+            buf[:n] = mine[:n]
+            allb = torch.empty((world * width, 24), dtype=torch.uint8, device=device)
             dist.all_gather_into_tensor(allb, buf, group=group)
-            allb = allb.cpu()
-            blocks = [allb[r * width: r * width + int(sizes[r])].numpy() for r in range(world)]
-        for blk in blocks:  # rank order = emission order
+            blocks_now = [allb[r * width: r * width + int(sizes[r])] for r in range(world)]
+        for blk in blocks_now:  # rank order = emission order
             kept.append(blk)
             total += len(blk)
-        e0 += per_rank * world
+        e0 += batch
     if total == 0:
         raise RuntimeError("photon map: no photon reached a photon surface")
-    rec = np.concatenate(kept)[:max_photons]
-    return scene.photon_install(rec)
+    rec = torch.cat(kept)[:max_photons].contiguous()
+    if device is not None:
+        torch.cuda.synchronize()
+    return scene.photon_install_ptr(rec.data_ptr(), len(rec))

@@ -114,6 +114,9 @@ int bhrt_scene_load_xml_ex(const char *path, int bvh_device, bhrt_scene **out);
 struct bhrt_bvh_node;
 int bhrt_bvh_build(const float *vertices, uint32_t n_vertices, const uint32_t *faces, uint32_t n_faces, uint32_t max_per_leaf, int device,
                    struct bhrt_bvh_node *nodes_out, uint32_t node_capacity, uint32_t *n_nodes, uint32_t *elems_out, uint32_t *depth);
+/* A second handle on the same loaded scene (host copy of the flattened scene, no device state): the reference's globals are
+ * one per process; a host that drives several GPUs keeps one handle per device (bhrt_scene_upload) — see csrc/bhrt_main.cpp. */
+int bhrt_scene_clone(const bhrt_scene *scene, bhrt_scene **out);
 void bhrt_scene_free(bhrt_scene *scene);
 int bhrt_scene_info(const bhrt_scene *scene, bhrt_info *info);
 int bhrt_scene_warning(const bhrt_scene *scene, uint32_t i, const char **text); /* the reference printf()s these */
@@ -138,6 +141,10 @@ int bhrt_trace_shadow_dev(bhrt_scene *scene, const float *d_rays_soa, const floa
  * radiance: W*H*3 floats, the per-pixel average BEFORE gamma (may be NULL).
  * Pixels of tiles owned by other ranks are left untouched.  Host pointers. */
 int bhrt_render(bhrt_scene *scene, const bhrt_opts *opts, uint8_t *rgb8, float *radiance, bhrt_stats *stats);
+/* Pinned (page-locked) host memory for the frame buffers handed to bhrt_render: the device-to-host copy then runs at the full PCIe
+ * rate (a pageable destination: about half).  Any host pointer works; this is only faster. */
+int bhrt_host_alloc(void **ptr, size_t bytes);
+void bhrt_host_free(void *ptr);
 /* same, but the outputs stay in HBM (device pointers; for timing and for the RCCL gather) */
 int bhrt_render_dev(bhrt_scene *scene, const bhrt_opts *opts, uint8_t *d_rgb8, float *d_radiance, bhrt_stats *stats, void *stream);
 /* per-sample radiance for a pixel region, keyed RNG (parity tests): out = region_pixels*spp*3 floats, host */
@@ -148,12 +155,13 @@ int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_pho
 /* Multi-GPU build of the caustic map: the emission loop of BuildCausticPhotonMap (Main.cpp:342-386) draws from
  * a stream keyed by the emission index, so ranks can run disjoint index ranges.  bhrt_photon_emit_range runs emissions
  * [e0, e0 + count) (count a multiple of 256) and returns the photons they store, in emission order, with unscaled power
- * (24-byte records, host pointer; *n_photons = how many, error if more than capacity).  bhrt_photon_install takes records in
+ * (24-byte records; photons_out may be a host or a device pointer — the records of a multi-GPU build never need to touch the host;
+ * *n_photons = how many, also when that is more than capacity: BHRT_ERR_ARG then, call again with room for them).  bhrt_photon_install takes records in
  * emission order (after the exchange: the first MAX_CausticPhotonCount of all ranks' records), applies ScalePhotonPowers(1/n)
  * (Main.cpp:380), balances and installs the map for bhrt_render* — the same map bhrt_photon_build makes alone. */
 int bhrt_photon_emit_range(bhrt_scene *scene, const bhrt_opts *opts, int global_map, uint64_t e0, uint32_t count, void *photons_out, uint32_t capacity,
                            uint32_t *n_photons);
-int bhrt_photon_install(bhrt_scene *scene, const void *records_emission_order, uint32_t n);
+int bhrt_photon_install(bhrt_scene *scene, const void *records_emission_order /* host or device pointer */, uint32_t n);
 /* The reference's second map, BuildPhotonMap (Main.cpp:251-295; TracePhotonRay Main.cpp:296-317, RandomPhotonBounce
  * MtlBlinn.cpp:140-202): photons that survive diffuse and specular bounces.  Its only call is commented out in the reference
  * (Main.cpp:196) and nothing gathers from it, so it is built on request and handed back: balanced 24-byte records into

@@ -21,7 +21,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define BHRT_HD __host__ __device__
 #else
 #define BHRT_HD
@@ -68,6 +68,16 @@ static inline BHRT_HD uint32_t bhrt_photon_key(uint32_t seed, uint64_t emission)
     uint32_t k = bhrt_photon_key_sequential(seed);
     k = bhrt_mix32(k ^ bhrt_mix32((uint32_t)emission + 0x3C6EF372U));
     return bhrt_mix32(k ^ bhrt_mix32((uint32_t)(emission >> 32) + 0x9E3779B9U));
+}
+
+/* Keyed photon stream of a 64-bit emission index: (key, first counter).  A 32-bit key alone gives 2^32 streams, and the ~2e7
+ * emissions of a 1 M-photon caustic map would then contain ~5e4 pairs that replay an identical path (birthday bound).  Emissions
+ * [65536 m, 65536 m + 65536) therefore share key(m) and take disjoint 2^16-draw windows of its counter: a 1 M-photon build uses a
+ * few hundred keys (collision probability ~1e-5), and two emissions never read the same (key, counter) pair. */
+static inline BHRT_HD void bhrt_photon_stream(uint32_t seed, uint64_t emission, uint32_t *key, uint32_t *counter)
+{
+    *key = bhrt_photon_key(seed, emission >> 16);
+    *counter = (uint32_t)(emission & 0xFFFFu) << 16;
 }
 
 /* the counter-th draw of stream `key`: an int in [0, BHRT_RAND_MAX] like rand() */

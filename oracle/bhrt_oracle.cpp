@@ -1742,7 +1742,7 @@ template <class M> struct PhotonTracer {
         rng.key = bhrt_photon_key_sequential(seed);
         rng.ctr = 0;
         while (pm.numStored < maxPhotons) {
-            if (keyed) { rng.key = bhrt_photon_key(seed, emitted); rng.ctr = 0; }
+            if (keyed) bhrt_photon_stream(seed, emitted, &rng.key, &rng.ctr);
             float rnd = rng.Rnd01();
             size_t i = 0;
             while (rnd > Color(pl[i]->intensity[0], pl[i]->intensity[1], pl[i]->intensity[2]).Gray() * pl[i]->size / sum && i < pl.size() - 1) i++;

@@ -83,3 +83,66 @@ def test_all_shipped_scenes_load(B):
                 assert "Cannot load file" in w or "texture" in w
     finally:
         os.chdir(cwd)
+
+
+def test_png_textures_of_every_bit_depth(B, tmp_path):
+    """Texture.cpp:76 decodes with lodepng::decode(..., LCT_RGB, 8), which accepts every colour type and bit depth; the front-end's own
+    reader has to deliver the same RGB8 texels (16-bit samples: the high byte; grey below 8 bits: scaled to 0..255; palettes of any
+    index width).  An interlaced file and a file with absurd dimensions are 'texture failed to load' warnings, not crashes."""
+    import struct, zlib
+    from PIL import Image
+    rng = np.random.RandomState(4)
+    W, H = 19, 7                                   # odd width: sub-byte rows end inside a byte
+    cases = {}
+    g8 = rng.randint(0, 256, (H, W)).astype(np.uint8)
+    for bits in (1, 2, 4):
+        v = (g8 >> (8 - bits)).astype(np.uint8)
+        rows = []
+        for y in range(H):
+            bitstr = "".join(format(int(x), f"0{bits}b") for x in v[y])
+            bitstr += "0" * (-len(bitstr) % 8)
+            rows.append(b"\x00" + bytes(int(bitstr[k:k + 8], 2) for k in range(0, len(bitstr), 8)))
+        cases[f"grey{bits}"] = ((0, bits, b"".join(rows)), np.repeat((v.astype(np.uint32) * 255 // ((1 << bits) - 1)).astype(np.uint8)[..., None], 3, 2))
+    g16 = rng.randint(0, 65536, (H, W)).astype(">u2")
+    cases["grey16"] = ((0, 16, b"".join(b"\x00" + g16[y].tobytes() for y in range(H))), np.repeat((g16 >> 8).astype(np.uint8)[..., None], 3, 2))
+    rgb16 = rng.randint(0, 65536, (H, W, 3)).astype(">u2")
+    cases["rgb16"] = ((2, 16, b"".join(b"\x00" + rgb16[y].tobytes() for y in range(H))), (rgb16 >> 8).astype(np.uint8))
+
+    def write_png(path, ctype, bits, raw, plte=None, interlace=0, w=W, h=H):
+        def chunk(t, d):
+            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+        data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bits, ctype, 0, 0, interlace))
+        if plte is not None:
+            data += chunk(b"PLTE", plte)
+        open(path, "wb").write(data + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+    pal = rng.randint(0, 256, (16, 3)).astype(np.uint8)
+    idx = rng.randint(0, 16, (H, W)).astype(np.uint8)
+    rows = []
+    for y in range(H):
+        nib = list(idx[y]) + [0] * (W % 2)
+        rows.append(b"\x00" + bytes((nib[k] << 4) | nib[k + 1] for k in range(0, len(nib), 2)))
+    expected = {k: v[1] for k, v in cases.items()}
+    for name, ((ctype, bits, raw), _) in cases.items():
+        write_png(tmp_path / f"{name}.png", ctype, bits, raw)
+    write_png(tmp_path / "pal4.png", 3, 4, b"".join(rows), plte=pal.tobytes())
+    expected["pal4"] = pal[idx]
+    Image.fromarray(rng.randint(0, 256, (H, W, 4)).astype(np.uint8), "RGBA").save(tmp_path / "rgba8.png")   # PIL's encoder: filters, several chunks
+    expected["rgba8"] = np.asarray(Image.open(tmp_path / "rgba8.png").convert("RGB"))
+    write_png(tmp_path / "interlaced.png", 0, 8, b"\x00" * 50, interlace=1)
+    write_png(tmp_path / "huge.png", 2, 8, b"\x00" * 64, w=1 << 30, h=1 << 30)
+    names = list(expected) + ["interlaced", "huge"]
+    mats = "".join(f'<material type="blinn" name="m{k}"><diffuse texture="{n}.png"/></material>' for k, n in enumerate(names))
+    objs = "".join(f'<object type="sphere" name="s{k}" material="m{k}"><translate x="{3 * k}"/></object>' for k in range(len(names)))
+    xml = tmp_path / "tex.xml"
+    xml.write_text(f"<xml><scene>{objs}{mats}<light type=\"point\" name=\"l\"><intensity value=\"1\"/><position z=\"9\"/></light></scene>"
+                   "<camera><position y=\"-9\"/><target z=\"0\"/><up z=\"1\"/><width value=\"8\"/><height value=\"8\"/></camera></xml>")
+    sc = B.Scene(str(xml))
+    fv = sc.flat_view()
+    assert len(fv.textures) == len(expected)
+    for t, name in zip(fv.textures, expected):
+        assert (t.width, t.height) == (W, H), name
+        texels = fv.np(t.off_data, W * H * 3, np.uint8).reshape(H, W, 3)
+        assert np.array_equal(texels, expected[name]), name
+    w = [x for x in sc.warnings() if "texture" in x]
+    assert len(w) == 2 and "interlaced.png" in w[0] and "huge.png" in w[1]

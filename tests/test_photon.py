@@ -268,3 +268,34 @@ def test_gpu_sharded_photon_build_equals_single_build(B, load_scene):
         sc.photon_emit_range(opts, 0, 100)          # not a multiple of 256
     with pytest.raises(B.BhrtError):
         sc.photon_emit_range(opts, 0, 4096, global_map=True, capacity=16)   # buffer too small
+
+
+@pytest.mark.gpu
+def test_gpu_photon_records_stay_on_the_device(B, load_scene):
+    """The multi-GPU build with device-resident exchange buffers (what dist.photon_build_sharded does under RCCL): emission writes
+    its records to a device pointer, they are strung together on the device and installed from a device pointer — and a buffer
+    that is too small reports how much room is needed.  World size 1 through photon_build_sharded(device=cuda) itself."""
+    import torch
+    import bhraytracer_amd.dist as BD
+    sc = load_scene("c5_caustics")
+    opts = B.default_opts(seed=7)
+    N = 30000
+    sc.photon_build(opts, N)
+    single = sc.photon_get().copy()
+    dev = torch.device("cuda", 0)
+    small = torch.zeros((16, 24), dtype=torch.uint8, device=dev)
+    n, ok = sc.photon_emit_range_into(opts, 0, 1 << 16, small.data_ptr(), 16)
+    assert not ok and n > 16 and not small.any()                  # nothing written, the needed size reported
+    parts, total, e0 = [], 0, 0
+    while total < N:
+        buf = torch.zeros((n + 4096, 24), dtype=torch.uint8, device=dev)
+        m, ok = sc.photon_emit_range_into(opts, e0, 1 << 16, buf.data_ptr(), len(buf))
+        assert ok
+        parts.append(buf[:m])
+        total += m
+        e0 += 1 << 16
+    rec = torch.cat(parts)[:N].contiguous()
+    torch.cuda.synchronize()
+    assert sc.photon_install_ptr(rec.data_ptr(), N) == N and np.array_equal(sc.photon_get(), single)
+    assert BD.photon_build_sharded(sc, opts, N, 0, 1, device=dev) == N and np.array_equal(sc.photon_get(), single)
+    assert BD.photon_build_sharded(sc, opts, N, 0, 1, device=None, batch=1 << 18) == N and np.array_equal(sc.photon_get(), single)
