@@ -245,6 +245,7 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
                          "queries_per_frame": agg.get("photon_queries", 0) / steps,
                          "heavy_queries_per_frame": agg.get("photon_heavy_queries", 0) / steps,
                          "wave_queries_per_frame": agg.get("photon_wave_queries", 0) / steps,
+                         "exact_replay_queries_per_frame": agg.get("photon_exact_queries", 0) / steps,
                          "nodes_visited_per_frame": agg.get("photon_nodes_visited", 0) / steps}
     return res
 

@@ -32,7 +32,7 @@ class Opts(C.Structure):
     _fields_ = [("spp", C.c_int32), ("gi_bounces", C.c_int32), ("internal_bounces", C.c_int32), ("seed", C.c_uint32),
                 ("jitter", C.c_int32), ("gamma", C.c_int32), ("photon_map", C.c_int32),
                 ("rank", C.c_int32), ("world_size", C.c_int32), ("tile_size", C.c_int32),
-                ("samples_per_pass", C.c_int32), ("timers", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("samples_per_pass", C.c_int32), ("timers", C.c_int32), ("photon_exact", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Stats(C.Structure):
@@ -65,7 +65,7 @@ EXPORTS = [
     "bhrt_photon_get", "bhrt_photon_export", "bhrt_photon_import", "bhrt_photon_build_global", "bhrt_save_png", "bhrt_math_eval_dev",
     "bhrt_tiles_block_bytes", "bhrt_tiles_pack_dev", "bhrt_tiles_unpack_dev",
     "bhrt_first_hit", "bhrt_first_hit_dev", "bhrt_zbuffer_image_dev", "bhrt_color_image_dev",
-    "bhrt_scene_load_xml_ex", "bhrt_bvh_build", "bhrt_photon_emit_range", "bhrt_photon_install", "bhrt_scene_clone", "bhrt_host_alloc", "bhrt_host_free",
+    "bhrt_scene_load_xml_ex", "bhrt_bvh_build", "bhrt_photon_emit_range", "bhrt_photon_install", "bhrt_scene_clone", "bhrt_host_alloc", "bhrt_host_free", "bhrt_photon_gather_host_ex",
 ]
 
 
@@ -243,13 +243,22 @@ class Scene:
         _check(lib().bhrt_photon_get(self._h, _ptr(out), n.value, C.byref(n)))
         return out
 
-    def photon_gather(self, p, nrm, radius=0.5):
+    def photon_gather(self, p, nrm, radius=0.5, exact=False):
+        """EstimateIrradiance<1000> for n points; exact: bhrt_opts.photon_exact (the reference's heap history replayed for heavy queries)."""
+        irr, d, _, _, _ = self.photon_gather_ex(p, nrm, radius, exact=exact, want_knn=False)
+        return irr, d
+
+    def photon_gather_ex(self, p, nrm, radius=0.5, exact=False, want_knn=True):
+        """photon_gather with the choice of bhrt_opts.photon_exact; returns (irr, dir, knn (cnt, 1000) uint32, knn_count (cnt,), d2max (cnt,))."""
         p = np.ascontiguousarray(p, np.float32)
         nrm = np.ascontiguousarray(nrm, np.float32)
-        irr = np.zeros_like(p)
-        d = np.zeros_like(p)
-        _check(lib().bhrt_photon_gather_host(self._h, _ptr(p), _ptr(nrm), C.c_size_t(p.shape[0]), C.c_float(radius), _ptr(irr), _ptr(d)))
-        return irr, d
+        irr, d = np.zeros_like(p), np.zeros_like(p)
+        cnt = p.shape[0]
+        knn = np.zeros((cnt, 1000), np.uint32) if want_knn else None
+        kc, dm = np.zeros(cnt, np.uint32), np.zeros(cnt, np.float32)
+        _check(lib().bhrt_photon_gather_host_ex(self._h, _ptr(p), _ptr(nrm), C.c_size_t(cnt), C.c_float(radius), 1 if exact else 0, _ptr(irr), _ptr(d),
+                                                _ptr(knn) if want_knn else None, _ptr(kc), _ptr(dm)))
+        return irr, d, knn, kc, dm
 
     def photon_emit_range(self, opts: Opts, e0: int, count: int, global_map: bool = False, capacity: int = 0) -> np.ndarray:
         """Emissions [e0, e0 + count): the photons they store, emission order, unscaled power, (n, 24) uint8 (multi-GPU build)."""

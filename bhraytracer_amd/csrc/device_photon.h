@@ -410,6 +410,296 @@ __device__ inline int photon_estimate_wave(const PhotonMapDev &M, WaveGatherLds 
     return 1;
 }
 
+// ---- heavy queries (>= 1000 acceptable photons inside the radius): the same SET as LocatePhotons, found by one wave --------
+// What the reference's heap replay (cyPhotonMap.h:439-497) ends up with.  Let A be the acceptable photons inside the radius (dist2 <
+// r^2, direction against the normal), in the order the walk meets them.  The first 1000, F, fill the list; the list becomes a max-heap;
+// the 1001st REPLACES THE ROOT UNCONDITIONALLY (np.dist2[0] is still r^2 at that moment), i.e. m = the farthest photon of F leaves whatever
+// the newcomer's distance; from then on np.dist2[0] is the heap's maximum and every further photon replaces the maximum iff it is
+// nearer — a plain streaming selection.  So the final list is the 1000 nearest of A - {m}, and its np.dist2[0] their largest distance.
+// With T = the 1001 nearest of A:  m is in T  <=>  every photon of F is in T  <=>  no photon of A outside T comes, in walk order, before
+// the second-to-last member of T.  Then the list is T - {m}; otherwise it is simply the 1000 nearest of A.
+//
+// One wave per query: the walk's SET of nodes does not depend on the visiting order, so the wave expands it 64 * BHRT_SEL_NPL nodes
+// per round from an LDS stack, with the shrinking bound of a k-nearest search (the 1001st nearest so far); candidates (dist2, photon,
+// path) are appended to a per-wave buffer and selected from registers — the reference's per-query candidate heap is 8 KB of dependent
+// global-memory accesses per replacement, which is what bounds the lane-per-query replay.  Walk order is recovered from the path alone: `sides` holds, most significant bit first, one bit
+// per level (1 = the far side was taken); with the node's depth that is its rank key (photon_walk_rank's, without the loads).
+// The float sums then run in candidate-buffer order, not in the reference's heap-array order: same photons, same area, the
+// irradiance equal to a few ulp (north_star's bar is 1e-4); bhrt_opts.photon_exact = 1 keeps the exact replay for every query.
+// Returns 0 = no photon, 1 = done, 4 = undecided (a bound-pruned walk that saw no photon of A - T early enough in walk order, or a
+// full stack): the caller hands the query to the exact replay.
+#ifndef BHRT_SEL_CAP
+#define BHRT_SEL_CAP 2048   /* candidates kept per query: 1001 + room between two compactions (a multiple of 64) */
+#endif
+#ifndef BHRT_SEL_STACK
+#define BHRT_SEL_STACK 768  /* 9 KB of LDS per wave: sixteen waves per CU */
+#endif
+#ifndef BHRT_SEL_SLACK
+#define BHRT_SEL_SLACK 64   /* a shed keeps between 1001 and 1001 + slack candidates */
+#endif
+#ifndef BHRT_SEL_NPL
+#define BHRT_SEL_NPL 1      /* nodes per lane and round (2: half the rounds, but twice the stack and registers: slower at equal occupancy) */
+#endif
+#ifndef BHRT_SEL_TRIGGER
+#define BHRT_SEL_TRIGGER 1280 /* candidates at which the far end is shed and the bound tightened: early and often — a compaction costs about
+                                 three rounds of the walk, a loose bound costs hundreds (everything inside the full radius is visited) */
+#endif
+#define BHRT_SEL_T (BHRT_PHOTON_K + 1)
+#define BHRT_SEL_SLOTS (BHRT_SEL_CAP / 64)
+// The walk's stack lives in LDS (8 KB per wave: occupancy is what hides the two dependent loads of a round; with the candidates in LDS as
+// well — 40 KB — a CU held four waves and the pass ran at a sixth of the lane pass's rate per node).  The candidates live in a scratch
+// of the wave in global memory: appended with coalesced stores, read back into registers — lane l holds entries l, l + 64, ... — when the
+// buffer is full, where the selection runs on registers only.
+struct SelectLds {
+    uint32_t st_node[BHRT_SEL_STACK], st_sides[BHRT_SEL_STACK];
+    float st_plane[BHRT_SEL_STACK]; // squared distance to the splitting plane that justified a far-side entry (0 for near-side entries)
+};
+#define BHRT_SEL_SPILL 4096 /* stack entries a wave can park in global memory when its LDS stack is full */
+#define BHRT_SEL_SPILL_CHUNK 256
+#define BHRT_SEL_SCRATCH_WORDS (3 * BHRT_SEL_CAP + 3 * BHRT_SEL_SPILL)
+struct SelectScratch { // BHRT_SEL_CAP entries each; sp_*: BHRT_SEL_SPILL entries each
+    uint32_t *d2, *idx, *sides;
+    uint32_t *sp_node, *sp_sides;
+    float *sp_plane;
+};
+// The LDS stack is full: its OLDEST BHRT_SEL_SPILL_CHUNK entries (far sides of the first levels: the least urgent) go to the wave's
+// spill area in global memory, the rest moves down.  false = the spill area is full as well.
+__device__ inline bool sel_spill(SelectLds &L, const SelectScratch &C, uint32_t &top, uint32_t &spilled, uint32_t lane)
+{
+    if (spilled + BHRT_SEL_SPILL_CHUNK > BHRT_SEL_SPILL || top < BHRT_SEL_SPILL_CHUNK) return false;
+    for (uint32_t k = lane; k < BHRT_SEL_SPILL_CHUNK; k += 64) {
+        C.sp_node[spilled + k] = L.st_node[k]; C.sp_sides[spilled + k] = L.st_sides[k]; C.sp_plane[spilled + k] = L.st_plane[k];
+    }
+    __syncthreads();
+    for (uint32_t b = 0; b + BHRT_SEL_SPILL_CHUNK < top; b += 64) { // chunk after chunk: each is read whole before it is written lower down
+        const uint32_t k = b + lane;
+        const bool in = k + BHRT_SEL_SPILL_CHUNK < top;
+        const uint32_t a = in ? L.st_node[k + BHRT_SEL_SPILL_CHUNK] : 0u, c = in ? L.st_sides[k + BHRT_SEL_SPILL_CHUNK] : 0u;
+        const float p = in ? L.st_plane[k + BHRT_SEL_SPILL_CHUNK] : 0.f;
+        __syncthreads();
+        if (in) { L.st_node[k] = a; L.st_sides[k] = c; L.st_plane[k] = p; }
+        __syncthreads();
+    }
+    top -= BHRT_SEL_SPILL_CHUNK;
+    spilled += BHRT_SEL_SPILL_CHUNK;
+    return true;
+}
+__device__ inline unsigned long long sel_key(uint32_t sides, uint32_t node)
+{
+    unsigned long long x = sides;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    const int depth = 31 - __clz((int)node);
+    return x | (2ull << (62 - 2 * depth));
+}
+__device__ inline uint32_t wave_sum_u32(uint32_t v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
+__device__ inline unsigned long long wave_min_u64(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(v, off); v = o < v ? o : v; }
+    return v;
+}
+__device__ inline unsigned long long wave_max_u64(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(v, off); v = o > v ? o : v; }
+    return v;
+}
+// the wave's candidate distances in registers: r[k] = entry lane + 64 k, or all ones beyond n (bit patterns of non-negative floats order like the floats)
+struct SelRegs { uint32_t r[BHRT_SEL_SLOTS]; };
+__device__ inline void sel_load(SelRegs &R, const SelectScratch &C, uint32_t n, uint32_t lane)
+{
+#pragma unroll
+    for (int k = 0; k < BHRT_SEL_SLOTS; k++) { const uint32_t j = lane + 64u * k; R.r[k] = j < n ? C.d2[j] : 0xffffffffu; }
+}
+__device__ inline uint32_t sel_count_below(const SelRegs &R, uint32_t pivot)
+{
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < BHRT_SEL_SLOTS; k++) c += R.r[k] < pivot ? 1u : 0u;
+    return wave_sum_u32(c);
+}
+// keeps the entries with d2 < pivot, and up to `ties` of those == pivot, in buffer order; folds the walk keys of the others into min_out.
+// In place: chunk k is read (a whole-wave load the stores of the chunk depend on) before anything at or below it is overwritten.
+__device__ inline uint32_t sel_compact(const SelRegs &R, const SelectScratch &C, uint32_t n, uint32_t pivot, uint32_t ties, unsigned long long &min_out, uint32_t lane)
+{
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t w = 0;
+    unsigned long long mk = ~0ull;
+#pragma unroll
+    for (int k = 0; k < BHRT_SEL_SLOTS; k++) {
+        if (64u * k >= n) break; // uniform
+        const uint32_t j = lane + 64u * k;
+        const bool in = j < n;
+        const uint32_t d = R.r[k], ix = in ? C.idx[j] : 0u, sd = in ? C.sides[j] : 0u;
+        const uint64_t mt = __ballot(in && d == pivot);
+        const bool keep = in && (d < pivot || (d == pivot && (uint32_t)__popcll(mt & lt) < ties));
+        const uint64_t mkp = __ballot(keep);
+        ties -= (uint32_t)__popcll(__ballot(keep && d == pivot));
+        if (in && !keep) { const unsigned long long key = sel_key(sd, ix); mk = key < mk ? key : mk; }
+        if (keep) { const uint32_t o = w + (uint32_t)__popcll(mkp & lt); C.d2[o] = d; C.idx[o] = ix; C.sides[o] = sd; }
+        w += (uint32_t)__popcll(mkp);
+    }
+    mk = wave_min_u64(mk);
+    min_out = mk < min_out ? mk : min_out;
+    return w;
+}
+__device__ inline int photon_estimate_select(const PhotonMapDev &M, SelectLds &L, const SelectScratch &C, V3 pos, V3 normal, float radius, V3 &irrad, V3 &direction,
+                                             uint32_t &visited, uint32_t *knn_out /* optional: BHRT_PHOTON_K + 2 words: count, bits of np.dist2[0], the photons */,
+                                             uint32_t *dbg /* rounds, compactions (per wave, lane-uniform) */)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const float r2 = radius * radius;
+    irrad = v3(0, 0, 0);
+    direction = v3(0, 0, 0);
+    if (M.n <= 0) return 0;
+    float bound = r2;
+    uint32_t top = 1, n = 0, spilled = 0;
+    bool pruned = false; // the bound has left r^2: the buffer no longer holds all of A
+    unsigned long long min_out = ~0ull; // smallest walk key among the photons of A seen and dropped
+    if (lane == 0) { L.st_node[0] = 1; L.st_sides[0] = 0; L.st_plane[0] = 0.f; }
+    __syncthreads();
+    while (top > 0 || spilled > 0) {
+        if (top == 0) { // the LDS stack ran empty: the last parked chunk comes back
+            spilled -= BHRT_SEL_SPILL_CHUNK;
+            for (uint32_t k = lane; k < BHRT_SEL_SPILL_CHUNK; k += 64) {
+                L.st_node[k] = C.sp_node[spilled + k]; L.st_sides[k] = C.sp_sides[spilled + k]; L.st_plane[k] = C.sp_plane[spilled + k];
+            }
+            top = BHRT_SEL_SPILL_CHUNK;
+            __syncthreads();
+        }
+        const uint32_t take = top < 64u * BHRT_SEL_NPL ? top : 64u * BHRT_SEL_NPL;
+        const uint32_t base = top - take;
+        top = base;
+        dbg[0]++;
+        uint32_t node[BHRT_SEL_NPL], sides[BHRT_SEL_NPL];
+        bool valid[BHRT_SEL_NPL];
+        float4 h[BHRT_SEL_NPL], c0[BHRT_SEL_NPL];
+#pragma unroll
+        for (int u = 0; u < BHRT_SEL_NPL; u++) {
+            const uint32_t e = base + lane + 64u * u;
+            valid[u] = e < base + take && L.st_plane[e] < bound; // a far side entered under a looser bound may be out of reach by now
+            node[u] = valid[u] ? L.st_node[e] : 1u;
+            sides[u] = valid[u] ? L.st_sides[e] : 0u;
+        }
+        __syncthreads(); // every lane has read its stack slots
+#pragma unroll
+        for (int u = 0; u < BHRT_SEL_NPL; u++) { h[u] = M.hot[node[u]]; c0[u] = M.cold[2 * (size_t)node[u]]; } // all loads of the round in flight together
+#pragma unroll
+        for (int u = 0; u < BHRT_SEL_NPL; u++) {
+            const uint32_t me = node[u];
+            bool push_near = false, push_far = false;
+            uint32_t nearc = 0;
+            float plane2 = 0.f;
+            if (valid[u] && (int)me < M.half) {
+                const int axis = (int)__float_as_uint(h[u].w);
+                const float dist = (axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z)) - (axis == 0 ? h[u].x : (axis == 1 ? h[u].y : h[u].z));
+                nearc = dist > 0 ? 2 * me + 1 : 2 * me;
+                push_near = true;
+                plane2 = dist * dist;
+                push_far = plane2 < bound;
+            }
+            visited += (uint32_t)__popcll(__ballot(valid[u])) * (lane == 0 ? 1u : 0u);
+            const float dist2 = length_sq(v3(h[u].x, h[u].y, h[u].z) - pos);
+            const bool accept = valid[u] && dist2 < bound && !(dot(v3(c0[u].x, c0[u].y, c0[u].z), normal) >= 0);
+            const uint64_t mn = __ballot(push_near), mf = __ballot(push_far), ma = __ballot(accept);
+            const uint32_t cn = (uint32_t)__popcll(mn), cf = (uint32_t)__popcll(mf);
+            if (top + cn + cf > BHRT_SEL_STACK && !sel_spill(L, C, top, spilled, lane)) return 4;
+            const uint32_t far_bit = 1u << __clz((int)me); // bit 31 - depth(me): the level decided at `me`, most significant bit first
+            // far sides below near sides: the near sides are popped first (the bound tightens before the far sides are looked at)
+            if (push_far) { const uint32_t o = top + (uint32_t)__popcll(mf & lt); L.st_node[o] = nearc ^ 1u; L.st_sides[o] = sides[u] | far_bit; L.st_plane[o] = plane2; }
+            if (push_near) { const uint32_t o = top + cf + (uint32_t)__popcll(mn & lt); L.st_node[o] = nearc; L.st_sides[o] = sides[u]; L.st_plane[o] = 0.f; }
+            top += cn + cf;
+            if (accept) { const uint32_t o = n + (uint32_t)__popcll(ma & lt); C.d2[o] = __float_as_uint(dist2); C.idx[o] = me; C.sides[o] = sides[u]; }
+            n += (uint32_t)__popcll(ma);
+        }
+        __syncthreads();
+        if (n >= BHRT_SEL_TRIGGER) {
+            static_assert(BHRT_SEL_TRIGGER + 64 * BHRT_SEL_NPL <= BHRT_SEL_CAP && BHRT_SEL_T + BHRT_SEL_SLACK < BHRT_SEL_TRIGGER, "selection buffer sizes");
+            // shed the far end: a pivot with 1001 <= #(d2 < pivot) <= 1001 + slack, by bisection on the bit patterns; the pivot is the new bound
+            SelRegs R;
+            sel_load(R, C, n, lane);
+            uint32_t lo = 0, hi = __float_as_uint(bound), pivot = hi; // #(d2 < hi) = n >= 1001 throughout
+            while (hi - lo > 1) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                const uint32_t c = sel_count_below(R, mid);
+                if (c < BHRT_SEL_T) lo = mid;
+                else { hi = mid; pivot = mid; if (c <= BHRT_SEL_T + BHRT_SEL_SLACK) break; }
+            }
+            n = sel_compact(R, C, n, pivot, 0u, min_out, lane);
+            dbg[1]++;
+            if (n >= BHRT_SEL_TRIGGER) return 4; // a few hundred candidates at exactly the same distance
+            bound = __uint_as_float(pivot);
+            pruned = true;
+        }
+    }
+    if (n == 0) return 0;
+    float d2max = r2; // np.dist2[0]: stays r^2 until the 1001st photon arrives
+    uint32_t drop = 0xffffffffu;
+    if (n >= BHRT_SEL_T) {
+        // T = the 1001 nearest: the 1001st smallest value is the largest lo with #(d2 < lo) < 1001
+        SelRegs R;
+        sel_load(R, C, n, lane);
+        uint32_t lo = 0, hi = __float_as_uint(bound); // #(d2 < hi) = n >= 1001; #(d2 < lo) < 1001
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (sel_count_below(R, mid) < BHRT_SEL_T) lo = mid; else hi = mid;
+        }
+        const uint32_t below = sel_count_below(R, lo);
+        n = sel_compact(R, C, n, lo, BHRT_SEL_T - below, min_out, lane); // now exactly 1001
+        // the two largest walk keys of T, the farthest member, and the farthest member apart from the last one in walk order
+        unsigned long long k1 = 0, far_all = 0;
+        for (uint32_t j = lane; j < n; j += 64) {
+            const unsigned long long k = sel_key(C.sides[j], C.idx[j]);
+            k1 = k > k1 ? k : k1;
+            const unsigned long long f = ((unsigned long long)C.d2[j] << 32) | j;
+            far_all = f > far_all ? f : far_all;
+        }
+        k1 = wave_max_u64(k1);
+        far_all = wave_max_u64(far_all);
+        unsigned long long k2 = 0, far_f = 0;
+        for (uint32_t j = lane; j < n; j += 64) {
+            const unsigned long long k = sel_key(C.sides[j], C.idx[j]);
+            if (k != k1) {
+                k2 = k > k2 ? k : k2;
+                const unsigned long long f = ((unsigned long long)C.d2[j] << 32) | j;
+                far_f = f > far_f ? f : far_f;
+            }
+        }
+        k2 = wave_max_u64(k2);
+        far_f = wave_max_u64(far_f);
+        if (min_out < k2) drop = (uint32_t)far_all;  // a photon outside T is among the first 1000 of the walk: the 1000 nearest
+        else if (!pruned) drop = (uint32_t)far_f;    // all of A was seen: F = T without its last member in walk order, m = F's farthest
+        else return 4;
+        float dm = 0;
+        for (uint32_t j = lane; j < n; j += 64) if (j != drop) dm = fmaxf(dm, __uint_as_float(C.d2[j]));
+        for (int off = 32; off > 0; off >>= 1) dm = fmaxf(dm, __shfl_xor(dm, off));
+        d2max = dm;
+    }
+    // sums over the list, candidate-buffer order: lane-strided partial sums, then a fixed butterfly
+    V3 sumI = v3(0, 0, 0), sumD = v3(0, 0, 0);
+    for (uint32_t j = lane; j < n; j += 64) {
+        if (j == drop) continue;
+        const size_t k = C.idx[j];
+        const float4 c0 = M.cold[2 * k], c1 = M.cold[2 * k + 1];
+        sumI = sumI + 1.f * v3(c1.x, c1.y, c1.z);
+        sumD = sumD + v3(c0.x, c0.y, c0.z) * (1.f * c0.w);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sumI = sumI + v3(__shfl_xor(sumI.x, off), __shfl_xor(sumI.y, off), __shfl_xor(sumI.z, off));
+        sumD = sumD + v3(__shfl_xor(sumD.x, off), __shfl_xor(sumD.y, off), __shfl_xor(sumD.z, off));
+    }
+    if (knn_out) {
+        if (lane == 0) { knn_out[0] = n - (drop != 0xffffffffu ? 1u : 0u); knn_out[1] = __float_as_uint(d2max); }
+        for (uint32_t j = lane; j < n; j += 64)
+            if (j != drop) knn_out[2 + (j > drop && drop != 0xffffffffu ? j - 1 : j)] = C.idx[j];
+    }
+    photon_finish(sumI, sumD, d2max, irrad, direction);
+    return 1;
+}
+
 // The full replay with the 1000-entry candidate heap (cyPhotonMap.h:439-497,353-365).  cand: this lane's scratch column,
 // element k at [k * stride]; one 8-byte entry = (bits of dist2) << 32 | photon index, so a sift step moves one word
 // (dist2 >= 0: the float order is the order of the bit patterns, but the comparisons below stay float comparisons).

@@ -1206,6 +1206,9 @@ __global__ void __launch_bounds__(kBlock) k_gather_cell_scatter(uint32_t q0, uin
 // photon are appended to `heavy` (pass 3), queries whose walk is longer than the lane budget to `longq` (pass 2).
 // order: optional permutation of the queries (cell-sorted, see above).
 #define BHRT_GATHER_LANE_BUDGET 4096
+#ifndef BHRT_SEL_WAVES_PER_CU
+#define BHRT_SEL_WAVES_PER_CU 16 /* selection pass: one-wave workgroups per CU = 4 per SIMD (128 VGPRs), 8 KB of LDS each */
+#endif
 __device__ inline void wave_append(bool flag, uint32_t value, uint32_t *list, uint32_t *count)
 {
     const uint64_t m = __ballot(flag);
@@ -1274,6 +1277,38 @@ __global__ void __launch_bounds__(kBlock) k_photon_gather_heap(Sink sink, const 
         const bool found = photon_estimate_heap(M, sink.pos(q), sink.nrm(q), radius, scr + (size_t)lane * BHRT_HEAP_COLUMN, 1, irr, d, visited);
         sink.done(q, found, irr, d);
     }
+    count_visited(visited, counts);
+}
+
+// Pass 3 (default): the heavy queries by wave-cooperative selection (photon_estimate_select), one wave per query; the waves pull
+// queries from a shared cursor (their costs differ by orders of magnitude).  Undecided queries go to `undecided` for the exact replay.
+// knn (test hook): per query of `heavy` order... indexed by the query id q: BHRT_PHOTON_K + 2 words each.
+template <class Sink>
+__global__ void __launch_bounds__(64, BHRT_SEL_WAVES_PER_CU / 4) k_photon_gather_select(Sink sink, const uint32_t *heavy, uint32_t n_heavy, PhotonMapDev M, float radius, uint32_t *undecided,
+                                                             uint32_t *counts /* [0] undecided, [1] cursor, [2..3] visited */, uint32_t *knn, uint32_t *scratch)
+{
+    __shared__ SelectLds lds;
+    __shared__ uint32_t s_next;
+    uint32_t visited = 0, dbg[2] = {0, 0};
+    SelectScratch C;
+    C.d2 = scratch + (size_t)blockIdx.x * BHRT_SEL_SCRATCH_WORDS; C.idx = C.d2 + BHRT_SEL_CAP; C.sides = C.idx + BHRT_SEL_CAP;
+    C.sp_node = C.sides + BHRT_SEL_CAP; C.sp_sides = C.sp_node + BHRT_SEL_SPILL; C.sp_plane = (float *)(C.sp_sides + BHRT_SEL_SPILL);
+    while (true) {
+        if (threadIdx.x == 0) s_next = atomicAdd(&counts[1], 1u);
+        __syncthreads();
+        const uint32_t i = s_next;
+        __syncthreads();
+        if (i >= n_heavy) break;
+        const uint32_t q = heavy[i];
+        V3 irr, d;
+        const int r = photon_estimate_select(M, lds, C, sink.pos(q), sink.nrm(q), radius, irr, d, visited, knn ? knn + (size_t)q * (BHRT_PHOTON_K + 2) : nullptr, dbg);
+        if (threadIdx.x == 0) {
+            if (r == 4) undecided[atomicAdd(&counts[0], 1u)] = q;
+            else sink.done(q, r == 1, irr, d);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { atomicAdd(&counts[4], dbg[0]); atomicAdd(&counts[5], dbg[1]); }
     count_visited(visited, counts);
 }
 
@@ -1356,6 +1391,9 @@ struct DeviceState {
     HostCounters *d_pub = nullptr; // the device's address of h_pub
     uint32_t pub_seq = 0;
     int timers = 0;                // bhrt_opts.timers of the running call
+    int photon_exact = 0;          // bhrt_opts.photon_exact of the running call
+    uint32_t *d_knn = nullptr;     // test hook of bhrt_photon_gather_host_ex: the selection pass's photon lists
+    uint32_t *d_sel = nullptr;     // candidate scratch of the selection pass's waves
     hipStream_t stream = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     struct PendingTimer { int e0, e1; double *acc; };
@@ -1399,7 +1437,7 @@ void DestroyDeviceState(DeviceState *d)
     fr(d->d_blob); fr(d->d_chain);
     for (int k = 0; k < 2; k++) { fr(d->d_rayf[k]); fr(d->d_rayu[k]); }
     fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_park); fr(d->d_seg); fr(d->d_cnt); fr(d->d_aux);
-    fr(d->d_frame_rgb); fr(d->d_frame_rad);
+    fr(d->d_frame_rgb); fr(d->d_frame_rad); fr(d->d_sel);
     fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_cells); fr(d->d_tile_sums);
     if (d->h_n_heavy) (void)hipHostFree(d->h_n_heavy);
     if (d->h_pub) (void)hipHostFree(d->h_pub);
@@ -1580,8 +1618,8 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
         D->heavy_cap = cnt;
     }
     if (!D->d_n_heavy) {
-        HIP_CHECK(hipMalloc(&D->d_n_heavy, 4 * sizeof(uint32_t))); // [0] heavy, [1] long, [2..3] nodes visited (64-bit)
-        HIP_CHECK(hipHostMalloc(&D->h_n_heavy, 4 * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&D->d_n_heavy, 8 * sizeof(uint32_t))); // [0] heavy, [1] long, [2..3] nodes visited (64-bit), [4] selection rounds, [5] compactions
+        HIP_CHECK(hipHostMalloc(&D->h_n_heavy, 8 * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc(&D->d_cells, (size_t)BHRT_GATHER_CELLS * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc(&D->d_tile_sums, (size_t)(BHRT_GATHER_CELLS / kScanTile + kScanBlock) * sizeof(uint32_t)));
     }
@@ -1629,24 +1667,44 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
         st->photon_nodes_visited += (uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32);
     }
     if (n_heavy == 0) return BHRT_OK;
-    const uint32_t heap_lanes = 1u << 20; // as many heaps in flight as possible: the pass is a chain of dependent accesses per query (65 k lanes: 1.8x slower)
-    int rc = EnsurePhotonScratch(D, std::min<uint32_t>(heap_lanes, (n_heavy + 4095u) & ~4095u));
-    if (rc) return rc;
     Timer t(D, st ? &st->seconds_photon_heavy : nullptr, 0);
-    HIP_CHECK(hipMemsetAsync(D->d_n_heavy + 2, 0, 2 * sizeof(uint32_t), D->stream));
-    const uint32_t chunk = std::min<uint32_t>(D->scr_lanes, heap_lanes);
-    for (uint32_t h0 = 0; h0 < n_heavy; h0 += chunk) {
-        const uint32_t m = std::min<uint32_t>(chunk, n_heavy - h0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_heap<Sink>), dim3((m + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, sink, D->d_heavy, h0, m,
-                           D->pm, radius, D->d_scr, (size_t)D->scr_lanes, D->d_n_heavy);
+    const uint32_t *exact_list = D->d_heavy;
+    uint32_t n_exact = n_heavy;
+    if (!D->photon_exact) {
+        // selection pass: one wave per query; d_long is free again: undecided queries
+        HIP_CHECK(hipMemsetAsync(D->d_n_heavy, 0, 8 * sizeof(uint32_t), D->stream));
+        const uint32_t sel_waves = 256u * BHRT_SEL_WAVES_PER_CU; // persistent one-wave workgroups, each with its scratch (candidates 24 KB + stack spill 48 KB)
+        if (!D->d_sel) HIP_CHECK(hipMalloc(&D->d_sel, (size_t)sel_waves * BHRT_SEL_SCRATCH_WORDS * sizeof(uint32_t)));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_select<Sink>), dim3(std::min<uint32_t>(n_heavy, sel_waves)), dim3(64), 0, D->stream, sink, D->d_heavy, n_heavy,
+                           D->pm, radius, D->d_long, D->d_n_heavy, D->d_knn, D->d_sel);
+        HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_n_heavy, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
+        HIP_CHECK(hipStreamSynchronize(D->stream));
+        if (st) st->photon_nodes_visited += (uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32);
+        if (getenv("BHRT_DEBUG_GATHER"))
+            fprintf(stderr, "select pass: %u queries, %llu nodes, %u rounds, %u compactions, %u undecided\n", n_heavy,
+                    (unsigned long long)((uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32)), D->h_n_heavy[4], D->h_n_heavy[5], D->h_n_heavy[0]);
+        exact_list = D->d_long;
+        n_exact = D->h_n_heavy[0];
+    }
+    if (n_exact) { // the reference's candidate-heap history replayed, one lane per query (bhrt_opts.photon_exact, and what the selection left undecided)
+        const uint32_t heap_lanes = 1u << 20; // as many heaps in flight as possible: the pass is a chain of dependent accesses per query (65 k lanes: 1.8x slower)
+        int rc = EnsurePhotonScratch(D, std::min<uint32_t>(heap_lanes, (n_exact + 4095u) & ~4095u));
+        if (rc) return rc;
+        HIP_CHECK(hipMemsetAsync(D->d_n_heavy + 2, 0, 2 * sizeof(uint32_t), D->stream));
+        const uint32_t chunk = std::min<uint32_t>(D->scr_lanes, heap_lanes);
+        for (uint32_t h0 = 0; h0 < n_exact; h0 += chunk) {
+            const uint32_t m = std::min<uint32_t>(chunk, n_exact - h0);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_heap<Sink>), dim3((m + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, sink, exact_list, h0, m,
+                               D->pm, radius, D->d_scr, (size_t)D->scr_lanes, D->d_n_heavy);
+        }
+        if (st) {
+            st->photon_exact_queries += n_exact;
+            HIP_CHECK(hipMemcpyAsync(D->h_n_heavy + 2, D->d_n_heavy + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
+            HIP_CHECK(hipStreamSynchronize(D->stream));
+            st->photon_nodes_visited += (uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32);
+        }
     }
     t.Stop();
-    if (st) {
-        st->photon_exact_queries += n_heavy;
-        HIP_CHECK(hipMemcpyAsync(D->h_n_heavy + 2, D->d_n_heavy + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
-        HIP_CHECK(hipStreamSynchronize(D->stream));
-        st->photon_nodes_visited += (uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32);
-    }
     return BHRT_OK;
 }
 
@@ -1687,6 +1745,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
     if (pass_samples < (uint32_t)o.spp) pass_samples = (uint32_t)o.spp;
     const uint32_t frames_per_sample = 6; // Shade() frames per camera sample; an overflow halves the pass and retries
     D->timers = o.timers;
+    D->photon_exact = o.photon_exact;
     int path_mode = 1; // the traversal's path in LDS: 1 = 16-bit pair indices, 2 = 32-bit (a mesh with 2^17 nodes or more), 0 = no (deeper than 32 levels)
     {
         const bhrt_mesh *hm = (const bhrt_mesh *)(scene->flat.blob.data() + H->off_meshes);
@@ -2459,32 +2518,55 @@ try {
 } catch (...) { return bhrt::AbiException(); }
 
 
-int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *nrm, size_t cnt, float radius, float *irrad, float *dir)
+int bhrt_photon_gather_host_ex(bhrt_scene *scene, const float *p, const float *nrm, size_t cnt, float radius, int photon_exact, float *irrad, float *dir,
+                               uint32_t *knn, uint32_t *knn_count, float *d2max)
 try {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
     DeviceState *D = scene->dev;
     D->timers = 0;
+    D->photon_exact = photon_exact;
     if (!D->d_photons) { SetError("photon map: call bhrt_photon_build first"); return BHRT_ERR_ARG; }
     if (!p || !nrm || !irrad || !dir) { SetError("null buffer"); return BHRT_ERR_ARG; }
     if (cnt == 0) return BHRT_OK;
-    const uint32_t chunk = 1u << 20;
-    float *d_buf = nullptr;
-    HIP_CHECK(hipMalloc(&d_buf, (size_t)chunk * 12 * sizeof(float)));
-    for (size_t b = 0; b < cnt; b += chunk) {
-        const uint32_t m = (uint32_t)std::min<size_t>(chunk, cnt - b);
-        HIP_CHECK(hipMemcpy(d_buf, p + b * 3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemcpy(d_buf + (size_t)chunk * 3, nrm + b * 3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice));
+    const uint32_t chunk = (knn || knn_count || d2max) ? 1u << 14 : 1u << 20;
+    struct Bufs { float *f = nullptr; uint32_t *knn = nullptr; DeviceState *D; ~Bufs() { (void)hipFree(f); (void)hipFree(knn); D->d_knn = nullptr; } } b;
+    b.D = D;
+    HIP_CHECK(hipMalloc(&b.f, (size_t)chunk * 12 * sizeof(float)));
+    float *d_buf = b.f;
+    const size_t kw = BHRT_PHOTON_K + 2;
+    std::vector<uint32_t> h_knn;
+    if (knn || knn_count || d2max) { HIP_CHECK(hipMalloc(&b.knn, (size_t)chunk * kw * sizeof(uint32_t))); h_knn.resize((size_t)chunk * kw); }
+    for (size_t c0 = 0; c0 < cnt; c0 += chunk) {
+        const uint32_t m = (uint32_t)std::min<size_t>(chunk, cnt - c0);
+        HIP_CHECK(hipMemcpy(d_buf, p + c0 * 3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d_buf + (size_t)chunk * 3, nrm + c0 * 3, (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice));
+        if (b.knn) HIP_CHECK(hipMemset(b.knn, 0, (size_t)m * kw * sizeof(uint32_t)));
+        D->d_knn = b.knn;
         const GatherToArrays sink = {d_buf, d_buf + (size_t)chunk * 3, d_buf + (size_t)chunk * 6, d_buf + (size_t)chunk * 9};
         rc = RunGather(D, sink, 0, m, radius, nullptr);
-        if (rc) { (void)hipFree(d_buf); return rc; }
+        D->d_knn = nullptr;
+        if (rc) return rc;
         HIP_CHECK(hipStreamSynchronize(D->stream));
-        HIP_CHECK(hipMemcpy(irrad + b * 3, d_buf + (size_t)chunk * 6, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(dir + b * 3, d_buf + (size_t)chunk * 9, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(irrad + c0 * 3, d_buf + (size_t)chunk * 6, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(dir + c0 * 3, d_buf + (size_t)chunk * 9, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (b.knn) {
+            HIP_CHECK(hipMemcpy(h_knn.data(), b.knn, (size_t)m * kw * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < m; i++) {
+                const uint32_t *row = &h_knn[(size_t)i * kw];
+                if (knn_count) knn_count[c0 + i] = row[0];
+                if (d2max) memcpy(&d2max[c0 + i], &row[1], 4);
+                if (knn) memcpy(knn + (c0 + i) * BHRT_PHOTON_K, row + 2, BHRT_PHOTON_K * sizeof(uint32_t));
+            }
+        }
     }
-    (void)hipFree(d_buf);
     return BHRT_OK;
 } catch (...) { return bhrt::AbiException(); }
+
+int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *nrm, size_t cnt, float radius, float *irrad, float *dir)
+{
+    return bhrt_photon_gather_host_ex(scene, p, nrm, cnt, radius, 0, irrad, dir, nullptr, nullptr, nullptr);
+}
 
 int bhrt_photon_get(const bhrt_scene *scene, void *photons_out, uint32_t capacity, uint32_t *n)
 try {

@@ -68,7 +68,10 @@ typedef struct bhrt_opts {
     int32_t samples_per_pass; /* 0 = choose; upper bound on camera samples in flight per wavefront pass */
     int32_t timers;           /* HIP-event kernel timers of bhrt_stats: 0 = seconds_shade only (default; an event between two kernels
                                * idles the GPU ~6 us), 1 = all kernel groups, -1 = none */
-    int32_t reserved[4];
+    int32_t photon_exact;     /* caustic gather of queries with >= 1000 photons inside the radius: 0 (default) = the same photon SET as
+                               * LocatePhotons (cyPhotonMap.h:421-498) found by a wave-cooperative selection, sums in a fixed order (irradiance
+                               * equal to a few ulp); 1 = the reference's candidate-heap history replayed lane by lane, identical bits, ~5x slower */
+    int32_t reserved[3];
 } bhrt_opts;
 
 typedef struct bhrt_stats {
@@ -169,6 +172,11 @@ int bhrt_photon_install(bhrt_scene *scene, const void *records_emission_order /*
 int bhrt_photon_build_global(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, void *photons_out, uint32_t capacity, uint32_t *n_stored,
                              const char *dat_path);
 int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *n, size_t cnt, float radius, float *irrad, float *dir);
+/* same with the choice of bhrt_opts.photon_exact, and (test hook, any pointer may be NULL) the photons the estimate used: knn = cnt x 1000
+ * indices into the balanced map (1-based, unsorted, unused slots 0), knn_count = how many, d2max = np.dist2[0] at the end of LocatePhotons.
+ * Filled for the queries the selection pass answers (>= 1000 photons in the radius, photon_exact = 0); knn_count = 0 otherwise. */
+int bhrt_photon_gather_host_ex(bhrt_scene *scene, const float *p, const float *n, size_t cnt, float radius, int photon_exact, float *irrad, float *dir,
+                               uint32_t *knn, uint32_t *knn_count, float *d2max);
 int bhrt_photon_get(const bhrt_scene *scene, void *photons_out /* 24 B records, balanced order */, uint32_t capacity, uint32_t *n);
 int bhrt_photon_export(const bhrt_scene *scene, const char *dat_path); /* 24-byte records, Main.cpp:383-385 */
 /* Loads a map written by bhrt_photon_export or by the reference (Resource/causticPhotonMap.dat) instead of building it.

@@ -1854,6 +1854,28 @@ extern "C" int oracle_photon_gather(const float *p, const float *nrm, size_t cnt
     return 0;
 }
 
+// The list LocatePhotons leaves behind (the photons the estimate sums, as indices into the balanced map, ascending), how many, and
+// np.dist2[0] at the end — what the HIP path's selection pass has to arrive at as a SET (tests/test_photon.py).
+extern "C" int oracle_photon_knn(const float *p, const float *nrm, size_t cnt, float radius, uint32_t *idx /* cnt x 1000 */, uint32_t *count, float *d2max)
+{
+    if (!g_photon_map) { g_err = "no photon map attached"; return 1; }
+    const int maxPhotons = 1000;
+    for (size_t i = 0; i < cnt; i++) {
+        float found_dist2[maxPhotons + 1];
+        int found_idx[maxPhotons + 1];
+        Nearest np;
+        np.pos = Vec3(p[i * 3], p[i * 3 + 1], p[i * 3 + 2]); np.normal = Vec3(nrm[i * 3], nrm[i * 3 + 1], nrm[i * 3 + 2]);
+        np.maxPhotons = maxPhotons; np.found = 0; np.dist2 = found_dist2; np.idx = found_idx;
+        np.dist2[0] = radius * radius;
+        if (g_photon_map->numStored > 0) LocatePhotons(*g_photon_map, np, 1);
+        std::sort(found_idx + 1, found_idx + 1 + np.found);
+        for (int k = 0; k < maxPhotons; k++) idx[i * maxPhotons + k] = k < np.found ? (uint32_t)found_idx[k + 1] : 0u;
+        count[i] = (uint32_t)np.found;
+        d2max[i] = np.dist2[0];
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // BeginRender() as a whole program (Main.cpp:178-242), the way the reference itself runs it with one OpenMP thread: ONE
 // rand() stream for the process (libc's global state), consumed first by BuildCausticPhotonMap (Main.cpp:195-198, -DUSE_PhotonMap

@@ -80,6 +80,10 @@ int oracle_photon_attach(const void *photons, uint32_t n);  /* n balanced (heap-
 int oracle_photon_balance(const void *emitted, uint32_t n, void *balanced_out); /* PrepareForIrradianceEstimation on n records */
 int oracle_photon_gather(const float *p, const float *nrm, size_t cnt, float radius, float *irrad, float *dir);
 
+/* the photons LocatePhotons (cyPhotonMap.h:421-498) ends up with: indices into the balanced map (1-based, ascending, 0-padded to 1000), their
+ * number, and np.dist2[0] */
+int oracle_photon_knn(const float *p, const float *nrm, size_t cnt, float radius, uint32_t *idx, uint32_t *count, float *d2max);
+
 /* BeginRender() as the reference's whole program runs it with one thread (Main.cpp:178-242): one rand() stream for the photon build
  * (photon_budget > 0: BuildCausticPhotonMap with that budget, Main.cpp:342-386, and the gather in Shade) and the pixel loop in
  * column-major order, opts->spp samples per pixel.  rgb8: W*H*3 = RenderImage::GetPixels().  photons_out: the balanced map. */

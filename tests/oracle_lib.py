@@ -170,6 +170,17 @@ def photon_gather(p, nrm, radius=0.5):
     return irr, d
 
 
+def photon_knn(p, nrm, radius=0.5):
+    """The list LocatePhotons ends with: (indices (n, 1000) ascending and 0-padded, count (n,), np.dist2[0] (n,))."""
+    p = np.ascontiguousarray(p, np.float32)
+    nrm = np.ascontiguousarray(nrm, np.float32)
+    idx = np.zeros((p.shape[0], 1000), np.uint32)
+    cnt = np.zeros(p.shape[0], np.uint32)
+    d2 = np.zeros(p.shape[0], np.float32)
+    _check(lib().oracle_photon_knn(_p(p), _p(nrm), C.c_size_t(p.shape[0]), C.c_float(radius), _p(idx), _p(cnt), _p(d2)))
+    return idx, cnt, d2
+
+
 def bvh_build(v, f, max_per_leaf=4):
     v = np.ascontiguousarray(v, np.float32)
     f = np.ascontiguousarray(f, np.uint32)

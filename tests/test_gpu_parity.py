@@ -354,6 +354,16 @@ def test_photon_frame_full_size_invariances(gpu, load_scene):
     assert n == 1000000
     first = sc.photon_get().copy()
     assert sc.photon_build(o, 1000000) == n and np.array_equal(sc.photon_get(), first)      # same map again, byte for byte
+    # the gather at full size: around the focus under the glass sphere one radius holds up to 10^5 photons -> the selection pass with its
+    # shrinking bound and repeated compactions; further out the plain walk.  Same photons as the oracle's LocatePhotons.
+    from test_photon import check_selected_photons
+    import oracle_lib as O
+    O.photon_attach(first)
+    rng = np.random.RandomState(21)
+    p = np.concatenate([rng.uniform([-13, -11, 0.0], [-5, -2, 0.0], (260, 3)), rng.uniform([-15, -20, 0.0], [15, 10, 0.0], (140, 3))]).astype(np.float32)
+    nrm = np.tile(np.float32([0, 0, 1]), (len(p), 1))
+    n_heavy, n_sel = check_selected_photons(sc, O, p, nrm, 0.5)
+    assert n_heavy > 50 and n_sel > 50
     o.photon_map = 1
     base_rgb, base_rad, st = sc.render(o)
     off_rgb, off_rad, _ = sc.render(gpu.default_opts(spp=1, gi_bounces=1, seed=2))

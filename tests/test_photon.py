@@ -92,6 +92,26 @@ def test_heap_mode_more_than_1000_candidates(load_scene, O):
 
 
 # ------------------------------------------------------------------------------------------------ GPU
+def check_selected_photons(sc, O, p, nrm, radius):
+    """The default gather (bhrt_opts.photon_exact = 0) against the oracle's LocatePhotons: queries with fewer than 1000 photons in the
+    radius keep the walk's own summation order (identical bits); the others must use exactly the reference's photons — the SET the heap
+    history ends with, including its quirk of throwing out the farthest of the first 1000 unconditionally — and its np.dist2[0]; their sums
+    run in another order, so the estimate is compared to a few ulp of the float sums (north_star: 1e-4 on radiance)."""
+    gi, gd, knn, kc, dm = sc.photon_gather_ex(p, nrm, radius)
+    oi, od = O.photon_gather(p, nrm, radius)
+    oidx, ocnt, od2 = O.photon_knn(p, nrm, radius)
+    heavy = ocnt >= 1000
+    assert same_bits(gi[~heavy], oi[~heavy]) and same_bits(gd[~heavy], od[~heavy])
+    sel = heavy & (kc > 0)                                   # answered by the selection pass (the rest went to the exact replay)
+    assert same_bits(gi[heavy & ~sel], oi[heavy & ~sel]) and same_bits(gd[heavy & ~sel], od[heavy & ~sel])
+    if heavy.any():
+        assert sel.sum() >= 0.9 * heavy.sum()
+        assert np.array_equal(kc[sel], ocnt[sel]) and same_bits(dm[sel], od2[sel])
+        assert np.array_equal(np.sort(knn[sel], axis=1), np.sort(oidx[sel], axis=1))
+        assert np.allclose(gi[sel], oi[sel], rtol=2e-5, atol=0) and np.allclose(gd[sel], od[sel], rtol=0, atol=2e-5)
+    return int(heavy.sum()), int(sel.sum())
+
+
 @pytest.mark.gpu
 def test_gpu_photon_map_vs_oracle(B, load_scene, O):
     if B.device_count() < 1:
@@ -110,9 +130,10 @@ def test_gpu_photon_map_vs_oracle(B, load_scene, O):
     nr = np.tile(np.float32([0, 0, 1]), (len(p), 1))
     nr[::9] = [0, 0, -1]
     for radius in (0.5, 2.5):
-        gi, gd = sc.photon_gather(p, nr, radius)
+        gi, gd = sc.photon_gather(p, nr, radius, exact=True)                # bhrt_opts.photon_exact: the heap history replayed
         oi, od = O.photon_gather(p, nr, radius)
         assert same_bits(gi, oi) and same_bits(gd, od)
+        check_selected_photons(sc, O, p, nr, radius)                        # default: the same photons, selected by a wave
     assert (oi.sum(1) > 0).sum() > 300
     # the three gather passes agree: lane walk only / every query by a whole wave (walk order rebuilt by rank sort) / default mix
     import os
@@ -125,8 +146,9 @@ def test_gpu_photon_map_vs_oracle(B, load_scene, O):
                 os.environ.pop("BHRT_GATHER_LANE_BUDGET", None)
             else:
                 os.environ["BHRT_GATHER_LANE_BUDGET"] = budget
-            gi, gd = sc.photon_gather(p, rn, radius)
+            gi, gd = sc.photon_gather(p, rn, radius, exact=True)
             assert same_bits(gi, oi) and same_bits(gd, od), (radius, budget)
+            check_selected_photons(sc, O, p, rn, radius)
     found = (oi.sum(1) > 0)
     assert found.sum() > 100 and (~found).sum() > 100
     # radiance with the caustic term
@@ -134,8 +156,11 @@ def test_gpu_photon_map_vs_oracle(B, load_scene, O):
     ropts = B.default_opts(spp=2, gi_bounces=2, seed=3, photon_map=1)
     gs, st = sc.render_samples(ropts, *region)
     ro = O.render(sc.flat_bytes(), sc.width, sc.height, 2, gi=2, seed=3, region=region, photon=1)
-    assert np.nanmax(np.abs(gs - ro["samples"])) <= 1e-4
-    assert same_bits(gs, ro["samples"])
+    assert np.nanmax(np.abs(gs - ro["samples"])) <= 1e-4                    # north_star's bar, selection pass for the heavy queries
+    ropts.photon_exact = 1
+    gx, stx = sc.render_samples(ropts, *region)
+    assert same_bits(gx, ro["samples"])                                     # the exact replay: identical bits
+    assert st.photon_heavy_queries == stx.photon_heavy_queries == stx.photon_exact_queries and st.photon_exact_queries <= st.photon_heavy_queries // 20
     off, _ = sc.render_samples(B.default_opts(spp=2, gi_bounces=2, seed=3), *region)
     assert not same_bits(gs, off)                                           # the caustic actually contributes here
     # export = the reference's .dat (24-byte records, Main.cpp:383-385)
@@ -145,18 +170,18 @@ def test_gpu_photon_map_vs_oracle(B, load_scene, O):
     assert np.array_equal(np.fromfile(path, np.uint8).reshape(-1, 24), bal)
     # import: as is (the cached photon pass) and through InitializePhotonMapByFile, which balances the records again
     # (cyPhotonMap.h:409-417)
-    ref_i, ref_d = sc.photon_gather(p, nr, 0.5)
+    ref_i, ref_d = sc.photon_gather(p, nr, 0.5, exact=True)
     sc2 = load_scene("c5_caustics")
     sc2.photon_import(path)
     assert np.array_equal(sc2.photon_get(), bal)
-    gi2, gd2 = sc2.photon_gather(p, nr, 0.5)
+    gi2, gd2 = sc2.photon_gather(p, nr, 0.5, exact=True)
     assert same_bits(gi2, ref_i) and same_bits(gd2, ref_d)
     sc2.photon_import(path, rebalance=True)
     rebal = O.photon_balance(bal)
     assert np.array_equal(sc2.photon_get(), rebal)
     O.photon_attach(rebal)
     oi3, od3 = O.photon_gather(p, nr, 0.5)
-    gi3, gd3 = sc2.photon_gather(p, nr, 0.5)
+    gi3, gd3 = sc2.photon_gather(p, nr, 0.5, exact=True)
     assert same_bits(gi3, oi3) and same_bits(gd3, od3)
     with pytest.raises(B.BhrtError):
         sc2.photon_import(path + ".missing")
@@ -209,12 +234,16 @@ def test_gpu_photon_map_on_random_scenes(B, O, tmp_path):
         nr = q.normal(size=(400, 3)).astype(np.float32)
         nr /= np.linalg.norm(nr, axis=1, keepdims=True)
         for radius in (0.5, 3.0):
-            gi_, gd = sc.photon_gather(p, nr, radius)
+            gi_, gd = sc.photon_gather(p, nr, radius, exact=True)
             oi, od = O.photon_gather(p, nr, radius)
             assert same_bits(gi_, oi) and same_bits(gd, od), (seed, radius)
-        gs, _ = sc.render_samples(B.default_opts(spp=1, gi_bounces=1, seed=seed, photon_map=1), 0, 0, sc.width, sc.height)
+            O.photon_attach(sc.photon_get())
+            check_selected_photons(sc, O, p, nr, radius)
+        gs, _ = sc.render_samples(B.default_opts(spp=1, gi_bounces=1, seed=seed, photon_map=1, photon_exact=1), 0, 0, sc.width, sc.height)
         rs = O.render(blob, sc.width, sc.height, 1, gi=1, seed=seed, region=(0, 0, sc.width, sc.height), photon=1)["samples"]
         assert same_bits(gs, rs), seed
+        gs, _ = sc.render_samples(B.default_opts(spp=1, gi_bounces=1, seed=seed, photon_map=1), 0, 0, sc.width, sc.height)
+        assert np.nanmax(np.abs(gs - rs)) <= 1e-4, seed
 
 
 @pytest.mark.gpu
