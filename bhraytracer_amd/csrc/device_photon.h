@@ -262,7 +262,7 @@ __device__ inline void photon_finish(V3 sumI, V3 sumD, float d2max, V3 &irrad, V
 // EstimateIrradiance<1000> for a query that meets fewer than 1000 photons: the candidate list never becomes a heap, so
 // the sums run in walk order and no list has to be kept.  Returns 0 = no photon, 1 = done, 2 = the 1000th photon was
 // met: the caller redoes this query with photon_estimate_heap (the sums then run in heap-array order); 3 = more than
-// `budget` photons visited without an answer: the caller hands the query to a whole wave (k_photon_gather_wave), so
+// `budget` photons visited without an answer: the caller hands the query to a whole wave (k_photon_gather_select), so
 // that one lane's long walk (a dense cluster inside the radius, most of it rejected) does not hold up its launch.
 __device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 normal, float radius, int budget, V3 &irrad, V3 &direction, uint32_t &visited)
 {
@@ -296,120 +296,6 @@ __device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 nor
     return 1;
 }
 
-// photon_estimate_fast by a whole wave (blockDim = 64).  Without the candidate heap the radius never shrinks, so the
-// SET of visited nodes does not depend on the visiting order: the wave expands the walk breadth-wise from an LDS
-// work stack (64 nodes per round), collects the accepted photons, and puts them back in walk order afterwards — the
-// walk visits near child, far child, then the node itself, so a node's rank is the string of its path digits
-// (0 = near, 1 = far) closed by a 2, compared left to right.  Then one lane adds them up in that order.
-// Returns 0 / 1 like photon_estimate_fast, or 2 = met 1000 photons (heap pass).  All 64 lanes must call it.
-#define BHRT_WAVE_STACK 2048
-struct WaveGatherLds {
-    uint32_t stack[BHRT_WAVE_STACK];
-    unsigned long long key[1024];
-    uint32_t node[1024];
-    float val[7][64]; // staging of 64 photons' cold data for the ordered sum
-};
-__device__ inline unsigned long long photon_walk_rank(const PhotonMapDev &M, V3 pos, uint32_t node)
-{
-    const int depth = 31 - __clz((int)node);
-    unsigned long long key = 0;
-    for (int i = 0; i < depth; i++) { // ancestor at depth i and the path's child below it
-        const uint32_t a = node >> (depth - i), c = node >> (depth - i - 1);
-        const float4 h = M.hot[a];
-        const int axis = (int)__float_as_uint(h.w);
-        const float dist = (axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z)) - (axis == 0 ? h.x : (axis == 1 ? h.y : h.z));
-        const uint32_t nearc = dist > 0 ? 2 * a + 1 : 2 * a;
-        key |= (unsigned long long)(c == nearc ? 0u : 1u) << (62 - 2 * i);
-    }
-    return key | (2ull << (62 - 2 * depth));
-}
-__device__ inline int photon_estimate_wave(const PhotonMapDev &M, WaveGatherLds &L, V3 pos, V3 normal, float radius, V3 &irrad, V3 &direction, uint32_t &visited /* lane 0's */)
-{
-    const uint32_t lane = threadIdx.x;
-    const uint64_t lt = (1ull << lane) - 1ull;
-    const float d2max = radius * radius;
-    irrad = v3(0, 0, 0);
-    direction = v3(0, 0, 0);
-    if (M.n <= 0) return 0;
-    uint32_t top = 1, n_acc = 0;
-    if (lane == 0) L.stack[0] = 1;
-    __syncthreads();
-    while (top > 0) {
-        const uint32_t take = top < 64u ? top : 64u;
-        top -= take;
-        visited += take;
-        bool push_near = false, push_far = false, accept = false;
-        uint32_t nearc = 0, me = 0;
-        if (lane < take) {
-            me = L.stack[top + lane];
-            const float4 h = M.hot[me];
-            if ((int)me < M.half) {
-                const int axis = (int)__float_as_uint(h.w);
-                const float dist = (axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z)) - (axis == 0 ? h.x : (axis == 1 ? h.y : h.z));
-                nearc = dist > 0 ? 2 * me + 1 : 2 * me;
-                push_near = true;
-                push_far = dist * dist < d2max;
-            }
-            const float dist2 = length_sq(v3(h.x, h.y, h.z) - pos);
-            if (dist2 < d2max) {
-                const float4 c0 = M.cold[2 * (size_t)me];
-                accept = !(dot(v3(c0.x, c0.y, c0.z), normal) >= 0);
-            }
-        }
-        __syncthreads(); // every lane has read its stack slot
-        const uint64_t mn = __ballot(push_near), mf = __ballot(push_far), ma = __ballot(accept);
-        const uint32_t cn = (uint32_t)__popcll(mn);
-        if (top + cn + (uint32_t)__popcll(mf) > BHRT_WAVE_STACK) return 3; // cannot happen for trees below 2^31 nodes (<= 64 * depth entries)
-        if (push_near) L.stack[top + (uint32_t)__popcll(mn & lt)] = nearc;
-        if (push_far) L.stack[top + cn + (uint32_t)__popcll(mf & lt)] = nearc ^ 1u;
-        top += cn + (uint32_t)__popcll(mf);
-        if (ma) {
-            if (n_acc + (uint32_t)__popcll(ma) >= BHRT_PHOTON_K) return 2;
-            if (accept) L.node[n_acc + (uint32_t)__popcll(ma & lt)] = me;
-            n_acc += (uint32_t)__popcll(ma);
-        }
-        __syncthreads();
-    }
-    if (n_acc == 0) return 0;
-    // walk order: rank keys, bitonic sort of the (key, node) pairs in LDS
-    uint32_t n_sort = 64;
-    while (n_sort < n_acc) n_sort <<= 1;
-    for (uint32_t i = lane; i < n_sort; i += 64) L.key[i] = i < n_acc ? photon_walk_rank(M, pos, L.node[i]) : ~0ull;
-    __syncthreads();
-    for (uint32_t k = 2; k <= n_sort; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = lane; t < n_sort / 2; t += 64) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j; // pair (i, i + j), ascending where (i & k) == 0
-                const unsigned long long a = L.key[i], b = L.key[p];
-                if ((a > b) == ((i & k) == 0)) {
-                    L.key[i] = b; L.key[p] = a;
-                    const uint32_t na = L.node[i]; L.node[i] = L.node[p]; L.node[p] = na;
-                }
-            }
-            __syncthreads();
-        }
-    // ordered sums, 64 photons staged at a time
-    V3 sumI = v3(0, 0, 0), sumD = v3(0, 0, 0);
-    for (uint32_t base = 0; base < n_acc; base += 64) {
-        const uint32_t m = n_acc - base < 64u ? n_acc - base : 64u;
-        if (lane < m) {
-            const size_t k = L.node[base + lane];
-            const float4 c0 = M.cold[2 * k], c1 = M.cold[2 * k + 1];
-            L.val[0][lane] = c0.x; L.val[1][lane] = c0.y; L.val[2][lane] = c0.z; L.val[3][lane] = c0.w;
-            L.val[4][lane] = c1.x; L.val[5][lane] = c1.y; L.val[6][lane] = c1.z;
-        }
-        __syncthreads();
-        if (lane == 0)
-            for (uint32_t i = 0; i < m; i++) {
-                sumI = sumI + 1.f * v3(L.val[4][i], L.val[5][i], L.val[6][i]);
-                sumD = sumD + v3(L.val[0][i], L.val[1][i], L.val[2][i]) * (1.f * L.val[3][i]);
-            }
-        __syncthreads();
-    }
-    if (lane == 0) photon_finish(sumI, sumD, d2max, irrad, direction);
-    return 1;
-}
-
 // ---- heavy queries (>= 1000 acceptable photons inside the radius): the same SET as LocatePhotons, found by one wave --------
 // What the reference's heap replay (cyPhotonMap.h:439-497) ends up with.  Let A be the acceptable photons inside the radius (dist2 <
 // r^2, direction against the normal), in the order the walk meets them.  The first 1000, F, fill the list; the list becomes a max-heap;
@@ -426,8 +312,12 @@ __device__ inline int photon_estimate_wave(const PhotonMapDev &M, WaveGatherLds 
 // per level (1 = the far side was taken); with the node's depth that is its rank key (photon_walk_rank's, without the loads).
 // The float sums then run in candidate-buffer order, not in the reference's heap-array order: same photons, same area, the
 // irradiance equal to a few ulp (north_star's bar is 1e-4); bhrt_opts.photon_exact = 1 keeps the exact replay for every query.
-// Returns 0 = no photon, 1 = done, 4 = undecided (a bound-pruned walk that saw no photon of A - T early enough in walk order, or a
-// full stack): the caller hands the query to the exact replay.
+// The same kernel takes the LONG walks of the lane pass (a dense cluster inside the radius that the normal test rejects: up to 4 * 10^5
+// nodes for a point on the glass sphere above the focus): when the walk ends with fewer than 1000 candidates the list never became a heap,
+// the reference summed in walk order, and so does this — the candidates are sorted by their walk keys (bitonic, in the LDS the stack no
+// longer needs) and added up in that order: identical bits.
+// Returns 0 = no photon, 1 = done, 4 = undecided (a bound-pruned walk that saw no photon of A - T early enough in walk order; a full
+// stack spill; exact_only and 1000 candidates): the caller hands the query to the exact replay.
 #ifndef BHRT_SEL_CAP
 #define BHRT_SEL_CAP 2048   /* candidates kept per query: 1001 + room between two compactions (a multiple of 64) */
 #endif
@@ -547,7 +437,7 @@ __device__ inline uint32_t sel_compact(const SelRegs &R, const SelectScratch &C,
 }
 __device__ inline int photon_estimate_select(const PhotonMapDev &M, SelectLds &L, const SelectScratch &C, V3 pos, V3 normal, float radius, V3 &irrad, V3 &direction,
                                              uint32_t &visited, uint32_t *knn_out /* optional: BHRT_PHOTON_K + 2 words: count, bits of np.dist2[0], the photons */,
-                                             uint32_t *dbg /* rounds, compactions (per wave, lane-uniform) */)
+                                             uint32_t *dbg /* rounds, compactions (per wave, lane-uniform) */, bool exact_only /* bhrt_opts.photon_exact */)
 {
     const uint32_t lane = threadIdx.x;
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -616,6 +506,7 @@ __device__ inline int photon_estimate_select(const PhotonMapDev &M, SelectLds &L
             n += (uint32_t)__popcll(ma);
         }
         __syncthreads();
+        if (exact_only && n >= BHRT_PHOTON_K) return 4;
         if (n >= BHRT_SEL_TRIGGER) {
             static_assert(BHRT_SEL_TRIGGER + 64 * BHRT_SEL_NPL <= BHRT_SEL_CAP && BHRT_SEL_T + BHRT_SEL_SLACK < BHRT_SEL_TRIGGER, "selection buffer sizes");
             // shed the far end: a pivot with 1001 <= #(d2 < pivot) <= 1001 + slack, by bisection on the bit patterns; the pivot is the new bound
@@ -636,6 +527,39 @@ __device__ inline int photon_estimate_select(const PhotonMapDev &M, SelectLds &L
         }
     }
     if (n == 0) return 0;
+    if (n < BHRT_PHOTON_K) {
+        // the list never became a heap: sums in walk order (cyPhotonMap.h:353-365 over np.photon[1..found] as LocatePhotons filled it)
+        static_assert(sizeof(SelectLds) >= 1024 * sizeof(unsigned long long), "the sort reuses the stack's LDS");
+        if (M.n >= (1 << 26)) return 4; // the candidate's position rides in the key's low 10 bits: free below 2^26 photons (depth <= 25)
+        unsigned long long *keys = reinterpret_cast<unsigned long long *>(&L);
+        uint32_t n_sort = 64;
+        while (n_sort < n) n_sort <<= 1;
+        __syncthreads();
+        for (uint32_t i = lane; i < n_sort; i += 64) keys[i] = i < n ? (sel_key(C.sides[i], C.idx[i]) | i) : ~0ull;
+        __syncthreads();
+        for (uint32_t k = 2; k <= n_sort; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = lane; t < n_sort / 2; t += 64) {
+                    const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), q = i | j; // pair (i, i + j), ascending where (i & k) == 0
+                    const unsigned long long a = keys[i], b = keys[q];
+                    if ((a > b) == ((i & k) == 0)) { keys[i] = b; keys[q] = a; }
+                }
+                __syncthreads();
+            }
+        V3 sumI = v3(0, 0, 0), sumD = v3(0, 0, 0);
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t m = n - base < 64u ? n - base : 64u;
+            float4 c0 = make_float4(0, 0, 0, 0), c1 = c0;
+            if (lane < m) { const size_t k = C.idx[(uint32_t)keys[base + lane] & 1023u]; c0 = M.cold[2 * k]; c1 = M.cold[2 * k + 1]; }
+            for (uint32_t i = 0; i < m; i++) { // every lane adds the same values in the same order
+                sumI = sumI + 1.f * v3(__shfl(c1.x, (int)i), __shfl(c1.y, (int)i), __shfl(c1.z, (int)i));
+                sumD = sumD + v3(__shfl(c0.x, (int)i), __shfl(c0.y, (int)i), __shfl(c0.z, (int)i)) * (1.f * __shfl(c0.w, (int)i));
+            }
+        }
+        __syncthreads();
+        photon_finish(sumI, sumD, r2, irrad, direction);
+        return 1;
+    }
     float d2max = r2; // np.dist2[0]: stays r^2 until the 1001st photon arrives
     uint32_t drop = 0xffffffffu;
     if (n >= BHRT_SEL_T) {

@@ -1245,26 +1245,7 @@ __global__ void __launch_bounds__(kBlock) k_photon_gather_fast(Sink sink, uint32
     wave_append(r == 3, q, longq, &counts[1]);
     count_visited(visited, counts);
 }
-// Pass 2: the long walks, one wave per query (photon_estimate_wave); blocks stride over the list until it is exhausted.
-template <class Sink>
-__global__ void __launch_bounds__(64) k_photon_gather_wave(Sink sink, const uint32_t *longq, PhotonMapDev M, float radius, uint32_t *heavy, uint32_t *counts)
-{
-    __shared__ WaveGatherLds lds;
-    const uint32_t n_long = counts[1];
-    uint32_t visited = 0;
-    for (uint32_t i = blockIdx.x; i < n_long; i += gridDim.x) {
-        const uint32_t q = longq[i];
-        V3 irr, d;
-        const int r = photon_estimate_wave(M, lds, sink.pos(q), sink.nrm(q), radius, irr, d, visited);
-        if (threadIdx.x == 0) {
-            if (r >= 2) heavy[atomicAdd(&counts[0], 1u)] = q;
-            else sink.done(q, r == 1, irr, d);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && visited) atomicAdd((unsigned long long *)(counts + 2), (unsigned long long)visited);
-}
-// Pass 3: the queries of heavy[h0, h0+cnt) with the full candidate heap, one scratch column per lane.
+// Exact replay: the queries of heavy[h0, h0+cnt) with the full candidate heap, one scratch column per lane.
 template <class Sink>
 __global__ void __launch_bounds__(kBlock) k_photon_gather_heap(Sink sink, const uint32_t *heavy, uint32_t h0, uint32_t cnt, PhotonMapDev M, float radius,
                                                                unsigned long long *scr, size_t stride, uint32_t *counts)
@@ -1280,12 +1261,14 @@ __global__ void __launch_bounds__(kBlock) k_photon_gather_heap(Sink sink, const 
     count_visited(visited, counts);
 }
 
-// Pass 3 (default): the heavy queries by wave-cooperative selection (photon_estimate_select), one wave per query; the waves pull
-// queries from a shared cursor (their costs differ by orders of magnitude).  Undecided queries go to `undecided` for the exact replay.
-// knn (test hook): per query of `heavy` order... indexed by the query id q: BHRT_PHOTON_K + 2 words each.
+// Pass 2: one wave per query (photon_estimate_select) for what the lane pass set aside — the heavy queries (>= 1000 photons in the
+// radius: wave-cooperative selection) and the long walks (walk-order sums of fewer than 1000 photons).  The waves pull queries from a
+// shared cursor (their costs differ by orders of magnitude).  Undecided queries go to `undecided` for the exact replay.
+// exact_only: heavy queries are not decided here (bhrt_opts.photon_exact).  knn (test hook): BHRT_PHOTON_K + 2 words per query id.
 template <class Sink>
-__global__ void __launch_bounds__(64, BHRT_SEL_WAVES_PER_CU / 4) k_photon_gather_select(Sink sink, const uint32_t *heavy, uint32_t n_heavy, PhotonMapDev M, float radius, uint32_t *undecided,
-                                                             uint32_t *counts /* [0] undecided, [1] cursor, [2..3] visited */, uint32_t *knn, uint32_t *scratch)
+__global__ void __launch_bounds__(64, BHRT_SEL_WAVES_PER_CU / 4) k_photon_gather_select(Sink sink, const uint32_t *heavy, uint32_t n_heavy, const uint32_t *longq, uint32_t n_long,
+                                                             PhotonMapDev M, float radius, uint32_t *undecided,
+                                                             uint32_t *counts /* [0] undecided, [1] cursor, [2..3] visited */, uint32_t *knn, uint32_t *scratch, int exact_only)
 {
     __shared__ SelectLds lds;
     __shared__ uint32_t s_next;
@@ -1298,10 +1281,11 @@ __global__ void __launch_bounds__(64, BHRT_SEL_WAVES_PER_CU / 4) k_photon_gather
         __syncthreads();
         const uint32_t i = s_next;
         __syncthreads();
-        if (i >= n_heavy) break;
-        const uint32_t q = heavy[i];
+        if (i >= n_heavy + n_long) break;
+        const uint32_t q = i < n_long ? longq[i] : heavy[i - n_long]; // the long walks first: the launch's tail is then made of short queries
         V3 irr, d;
-        const int r = photon_estimate_select(M, lds, C, sink.pos(q), sink.nrm(q), radius, irr, d, visited, knn ? knn + (size_t)q * (BHRT_PHOTON_K + 2) : nullptr, dbg);
+        const int r = photon_estimate_select(M, lds, C, sink.pos(q), sink.nrm(q), radius, irr, d, visited, knn ? knn + (size_t)q * (BHRT_PHOTON_K + 2) : nullptr, dbg,
+                                             exact_only != 0);
         if (threadIdx.x == 0) {
             if (r == 4) undecided[atomicAdd(&counts[0], 1u)] = q;
             else sink.done(q, r == 1, irr, d);
@@ -1651,54 +1635,56 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
     HIP_CHECK(hipMemsetAsync(D->d_n_heavy, 0, 4 * sizeof(uint32_t), D->stream));
     int lane_budget = BHRT_GATHER_LANE_BUDGET;
     if (const char *e = getenv("BHRT_GATHER_LANE_BUDGET")) lane_budget = std::max(1, atoi(e)); // test knob: a tiny budget sends every query through pass 2
-    if (n_walk > 0) {
+    if (n_walk > 0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_fast<Sink>), grid, block, 0, D->stream, sink, q0, n_walk, order, D->pm, radius, lane_budget, D->d_heavy,
                            D->d_long, D->d_n_heavy);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_wave<Sink>), dim3(std::min<uint32_t>(n_walk, 2048u)), dim3(64), 0, D->stream, sink, D->d_long, D->pm, radius,
-                           D->d_heavy, D->d_n_heavy);
-    }
     HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_n_heavy, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
     HIP_CHECK(hipStreamSynchronize(D->stream));
-    const uint32_t n_heavy = D->h_n_heavy[0];
+    const uint32_t n_heavy = D->h_n_heavy[0], n_long = D->h_n_heavy[1];
     if (st) {
         st->photon_queries += cnt;
-        st->photon_wave_queries += D->h_n_heavy[1];
+        st->photon_wave_queries += n_long;
         st->photon_heavy_queries += n_heavy;
         st->photon_nodes_visited += (uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32);
     }
-    if (n_heavy == 0) return BHRT_OK;
+    if (n_heavy + n_long == 0) return BHRT_OK;
     Timer t(D, st ? &st->seconds_photon_heavy : nullptr, 0);
-    const uint32_t *exact_list = D->d_heavy;
-    uint32_t n_exact = n_heavy;
-    if (!D->photon_exact) {
-        // selection pass: one wave per query; d_long is free again: undecided queries
+    // pass 2, one wave per query: the long walks always; the heavy queries unless the exact replay is asked for.  Undecided ones go to a list of
+    // their own (d_cell_of is free again after the cell sort)
+    const uint32_t n_sel_heavy = D->photon_exact ? 0u : n_heavy;
+    uint32_t *undecided = D->d_cell_of;
+    uint32_t n_exact = 0;
+    if (n_sel_heavy + n_long) {
         HIP_CHECK(hipMemsetAsync(D->d_n_heavy, 0, 8 * sizeof(uint32_t), D->stream));
         const uint32_t sel_waves = 256u * BHRT_SEL_WAVES_PER_CU; // persistent one-wave workgroups, each with its scratch (candidates 24 KB + stack spill 48 KB)
         if (!D->d_sel) HIP_CHECK(hipMalloc(&D->d_sel, (size_t)sel_waves * BHRT_SEL_SCRATCH_WORDS * sizeof(uint32_t)));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_select<Sink>), dim3(std::min<uint32_t>(n_heavy, sel_waves)), dim3(64), 0, D->stream, sink, D->d_heavy, n_heavy,
-                           D->pm, radius, D->d_long, D->d_n_heavy, D->d_knn, D->d_sel);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_select<Sink>), dim3(std::min<uint32_t>(n_sel_heavy + n_long, sel_waves)), dim3(64), 0, D->stream, sink, D->d_heavy,
+                           n_sel_heavy, D->d_long, n_long, D->pm, radius, undecided, D->d_n_heavy, D->d_knn, D->d_sel, D->photon_exact);
         HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_n_heavy, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
         HIP_CHECK(hipStreamSynchronize(D->stream));
         if (st) st->photon_nodes_visited += (uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32);
         if (getenv("BHRT_DEBUG_GATHER"))
-            fprintf(stderr, "select pass: %u queries, %llu nodes, %u rounds, %u compactions, %u undecided\n", n_heavy,
+            fprintf(stderr, "select pass: %u heavy + %u long queries, %llu nodes, %u rounds, %u compactions, %u undecided\n", n_sel_heavy, n_long,
                     (unsigned long long)((uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32)), D->h_n_heavy[4], D->h_n_heavy[5], D->h_n_heavy[0]);
-        exact_list = D->d_long;
         n_exact = D->h_n_heavy[0];
     }
-    if (n_exact) { // the reference's candidate-heap history replayed, one lane per query (bhrt_opts.photon_exact, and what the selection left undecided)
+    // the reference's candidate-heap history replayed, one lane per query: what pass 2 left undecided, and (bhrt_opts.photon_exact) every heavy query
+    for (int part = 0; part < 2; part++) {
+        const uint32_t *list = part == 0 ? undecided : D->d_heavy;
+        const uint32_t m_all = part == 0 ? n_exact : (D->photon_exact ? n_heavy : 0u);
+        if (!m_all) continue;
         const uint32_t heap_lanes = 1u << 20; // as many heaps in flight as possible: the pass is a chain of dependent accesses per query (65 k lanes: 1.8x slower)
-        int rc = EnsurePhotonScratch(D, std::min<uint32_t>(heap_lanes, (n_exact + 4095u) & ~4095u));
+        int rc = EnsurePhotonScratch(D, std::min<uint32_t>(heap_lanes, (m_all + 4095u) & ~4095u));
         if (rc) return rc;
         HIP_CHECK(hipMemsetAsync(D->d_n_heavy + 2, 0, 2 * sizeof(uint32_t), D->stream));
         const uint32_t chunk = std::min<uint32_t>(D->scr_lanes, heap_lanes);
-        for (uint32_t h0 = 0; h0 < n_exact; h0 += chunk) {
-            const uint32_t m = std::min<uint32_t>(chunk, n_exact - h0);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_heap<Sink>), dim3((m + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, sink, exact_list, h0, m,
+        for (uint32_t h0 = 0; h0 < m_all; h0 += chunk) {
+            const uint32_t m = std::min<uint32_t>(chunk, m_all - h0);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_heap<Sink>), dim3((m + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, sink, list, h0, m,
                                D->pm, radius, D->d_scr, (size_t)D->scr_lanes, D->d_n_heavy);
         }
         if (st) {
-            st->photon_exact_queries += n_exact;
+            st->photon_exact_queries += m_all;
             HIP_CHECK(hipMemcpyAsync(D->h_n_heavy + 2, D->d_n_heavy + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
             HIP_CHECK(hipStreamSynchronize(D->stream));
             st->photon_nodes_visited += (uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32);
