@@ -43,7 +43,7 @@ class Stats(C.Structure):
                 ("launches_trace_closest", C.c_uint64), ("launches_trace_shadow", C.c_uint64),
                 ("seconds_photon_gather", C.c_double), ("seconds_photon_heavy", C.c_double),
                 ("photon_queries", C.c_uint64), ("photon_heavy_queries", C.c_uint64), ("photon_wave_queries", C.c_uint64),
-                ("photon_exact_queries", C.c_uint64), ("photon_nodes_visited", C.c_uint64),
+                ("photon_exact_queries", C.c_uint64), ("photon_nodes_visited", C.c_uint64), ("deferred_rays", C.c_uint64),
                 ("reserved", C.c_double * 4)]
 
     def as_dict(self):

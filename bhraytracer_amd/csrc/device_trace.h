@@ -463,9 +463,17 @@ __device__ inline bool mesh_closest_vote(const MeshRef &M, V3 o, V3 d, int side,
     int depth = 0;
     uint32_t inFar = 0, nearHit = 0, sides = 0;
     bool r = false, any = false;
+#ifdef BHRT_DEBUG_LONG_RAYS
+    uint32_t dbg_round = 0, dbg_mine = 0, dbg_desc = 0, dbg_leaf = 0;
+#endif
     while (true) {
         const int nD = __popcll(__ballot(st == 0)), nL = __popcll(__ballot(st == 1)), nC = __popcll(__ballot(st == 2));
         if (nD + nL + nC == 0) break;
+#ifdef BHRT_DEBUG_LONG_RAYS
+        dbg_round++;
+        if (st != 3) dbg_mine = dbg_round;
+        if (nD >= nL && nD >= nC) { if (st == 0) dbg_desc++; } else if (nL >= nC) { if (st == 1) dbg_leaf++; }
+#endif
         if (nD >= nL && nD >= nC) {
             if (st == 0) {
                 const uint32_t c1 = data & 0x7fffffffu;
@@ -541,6 +549,9 @@ __device__ inline bool mesh_closest_vote(const MeshRef &M, V3 o, V3 d, int side,
             }
         }
     }
+#ifdef BHRT_DEBUG_LONG_RAYS
+    if (dbg_mine > 20000u) printf("long ray: %u rounds (%u descend steps, %u leaves) o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) side %d hit t=%.9g prim %d\n", dbg_mine, dbg_desc, dbg_leaf, o.x, o.y, o.z, d.x, d.y, d.z, side, ht, hprim);
+#endif
     return any;
 }
 
@@ -740,10 +751,15 @@ __device__ inline uint32_t park_spread(uint32_t v) // low bits -> every third bi
 // 5, C2 trace 1.13 -> 0.90 ms).
 // path != nullptr: this lane's column of the LDS path stack (stride path_stride, 33 rows) -> mesh_closest_vote; the caller has
 // checked that every mesh qualifies.  lds_nodes: size of the nodelet buffer behind `lds`.
+// park_slow (park only): set when the parked ray has a zero direction component in the mesh's space.  Box::IntersectRay leaves such an
+// axis out (Box.cpp:13-28), so a ray parallel to one coordinate axis "hits" every box whose extent on that axis it
+// crosses — the reference walks (nearly) the whole tree for it, and so does the traversal here: ~10^5 sequential rounds for the
+// 100 k-triangle mesh.  The samplers produce such rays at a rate of ~1.5e-8 per diffuse GI ray off an axis-aligned wall (a 31-bit draw
+// below 2^-25 makes theta exactly 0 in GetSampleInSemiSphere, MtlBlinn.cpp:697-716: the ray leaves along the normal).
 template <bool kMeshes = true, class PathT = uint16_t>
 __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit &h, bool active = true, bhrt_bvh_node *lds = nullptr, int start = 0,
                                     bool park = false, uint32_t *park_key = nullptr, PathT *path = nullptr, uint32_t path_stride = 0,
-                                    uint32_t lds_nodes = BHRT_LDS_NODES, bool camera = false /* o = the camera position */)
+                                    uint32_t lds_nodes = BHRT_LDS_NODES, bool camera = false /* o = the camera position */, bool *park_slow = nullptr)
 {
     if (start == 0) { h.t = BHRT_BIGFLOAT; h.node = -1; h.prim = -1; h.front = 1; }
     int parked = -1;
@@ -772,6 +788,7 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
             const NodeRec root = node_at(M, 1);
             if (box_hit_rcp(root.b, lp, ld, ray_rcp(ld), h.t, tm)) {
                 parked = n;
+                if (park_slow) *park_slow = ld.x == 0 || ld.y == 0 || ld.z == 0;
                 if (park_key) { // ordering hint only: any value is correct
                     const V3 e = tm > 0 ? lp + tm * ld : lp;
                     const float nn = (float)(1 << BHRT_PARK_CELL_BITS), m = nn - 1.f;

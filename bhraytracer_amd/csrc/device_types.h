@@ -95,6 +95,7 @@ struct Counters {
     Line overflow;  // set when a capacity was exceeded
     // traced rays sorted for shading: class x shard element counts (see RayOrder)
     Line cls[4][BHRT_ORDER_SHARDS];
+    Line n_slow;    // rays set aside in the slow queue (kernels.hip::SlowQueue), this pass
 };
 #define BHRT_COUNTERS_HOST_BYTES (4 * 128)
 

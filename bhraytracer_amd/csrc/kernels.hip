@@ -255,8 +255,19 @@ __device__ inline uint32_t shading_class(uint32_t meta, const Hit &hit)
 // Closest hit of every queued ray.  meta == nullptr: every ray uses `uniform_side` (public bhrt_trace_closest_*).
 // kPark (scenes with meshes, render path): rays that reach a mesh whose root box they hit are parked on list RC_MESH
 // with their state in the hit buffer (front = front | (node + 1) << 8) and finished by k_trace_mesh.
+// Rays set aside by k_trace_closest<kPark>: parallel to a coordinate axis of the mesh they enter (trace_closest::park_slow).  One of them
+// keeps a single lane busy for up to ~100 ms on the 100 k-triangle mesh while the launch's other 10^7 rays are done after a few ms — and the
+// wave step cannot end before it.  They are taken out of their wave step and traced by k_trace_slow on a second stream while the pass goes
+// on; when the pass's queue has run empty they are moved into it with their hits and shaded, and their paths continue in wave steps of
+// their own.  Nothing about a path depends on WHEN its rays are traced: same hit records, same frames, same radiance bits.
+struct SlowQueue {
+    RayQueue q;
+    uint32_t cap;
+};
+constexpr uint32_t kSlowCap = 1u << 16; // per pass; rays beyond it are simply traced in their own wave step
 template <bool kPark, bool kCamera, bool kMeshes = true>
-__global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, PassInfo P, RayQueue q, uint32_t n, int uniform_side, HitBuf h, RayOrder ord, Counters *cnt)
+__global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, PassInfo P, RayQueue q, uint32_t n, int uniform_side, HitBuf h, RayOrder ord, Counters *cnt,
+                                                          SlowQueue slow /* cap 0: nothing is set aside */)
 {
     __shared__ bhrt_bvh_node nodelet[(kPark || !kMeshes) ? 1 : BHRT_LDS_NODES]; // top BVH levels of the mesh being traversed (device_trace.h)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -269,8 +280,20 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, PassInfo P
     const bool dead = has_meta && (meta & 15u) == RK_DEAD;
     Hit hit;
     uint32_t key = 0;
-    const int parked = trace_closest<kMeshes>(S, o, d, side, hit, active && !dead, (kPark || !kMeshes) ? nullptr : nodelet, 0, kPark, kPark ? &key : nullptr,
-                                              (uint16_t *)nullptr, 0, BHRT_LDS_NODES, kCamera); // uniform call: the block stages nodelets together
+    bool is_slow = false;
+    int parked = trace_closest<kMeshes>(S, o, d, side, hit, active && !dead, (kPark || !kMeshes) ? nullptr : nodelet, 0, kPark, kPark ? &key : nullptr,
+                                        (uint16_t *)nullptr, 0, BHRT_LDS_NODES, kCamera, kPark ? &is_slow : nullptr); // uniform call: the block stages nodelets together
+    if (kPark && parked >= 0 && is_slow && slow.cap) {
+        const uint32_t k = atomicAdd(&cnt->n_slow.v, 1u);
+        if (k < slow.cap) { // the ray as a queue entry of its own (a camera ray: owner = its sample slot); traced from scratch in the slow steps
+            slow.q.ox[k] = o.x; slow.q.oy[k] = o.y; slow.q.oz[k] = o.z; slow.q.dx[k] = d.x; slow.q.dy[k] = d.y; slow.q.dz[k] = d.z;
+            slow.q.frame[k] = kCamera ? i : q.frame[i];
+            slow.q.meta[k] = meta;
+            slow.q.rng_ctr[k] = (kCamera || (meta & 15u) == RK_GI) ? 0u : q.rng_ctr[i];
+            active = false; // not a ray of this wave step any more: neither finished nor filed for shading
+            parked = -1;
+        }
+    }
     if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front | ((parked + 1) << 8); }
     if (kPark && parked >= 0) {
         ord.park_key[i] = key;
@@ -396,6 +419,36 @@ __global__ void __launch_bounds__(kBlock) k_file_parked(RayQueue q, HitBuf h, Ra
     file_ray(cls, active ? i : 0u, blockIdx.x & (BHRT_ORDER_SHARDS - 1), ord, cnt);
 }
 
+// The rays of the slow queue [a, b), traced to the end (scene graph and meshes inline) on a stream of their own while the pass goes on:
+// one wave per 64 of them — they are few, and each is a walk of up to the whole BVH.
+template <int kPath>
+__global__ void __launch_bounds__(64) k_trace_slow(DevScene S, SlowQueue slow, uint32_t a, uint32_t b, HitBuf h)
+{
+    typedef typename std::conditional<kPath == 2, uint32_t, uint16_t>::type PathT;
+    __shared__ PathT path[kPath ? 33 * 64 : 1];
+    __builtin_amdgcn_s_setprio(3); // one long chain of dependent steps beside a full GPU: first in line for its SIMD's issue slots
+    const uint32_t i = a + blockIdx.x * 64 + threadIdx.x;
+    const bool active = i < b;
+    V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
+    uint32_t meta = 0;
+    if (active) { o = v3(slow.q.ox[i], slow.q.oy[i], slow.q.oz[i]); d = v3(slow.q.dx[i], slow.q.dy[i], slow.q.dz[i]); meta = slow.q.meta[i]; }
+    Hit hit;
+    trace_closest<true, PathT>(S, o, d, (int)((meta >> 4) & 3u), hit, active, nullptr, 0, false, nullptr, kPath ? path + threadIdx.x : (PathT *)nullptr, 64, 0);
+    if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; }
+}
+// Files rays whose hits are already there (the slow queue, moved into the ray queue) for shading.
+__global__ void __launch_bounds__(kBlock) k_file_all(RayQueue q, HitBuf h, uint32_t n, RayOrder ord, Counters *cnt)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cls = RC_NONE;
+    if (i < n) {
+        Hit hit;
+        hit.t = h.t[i]; hit.node = h.node[i]; hit.prim = h.prim[i]; hit.front = h.front[i];
+        cls = shading_class(q.meta[i], hit);
+    }
+    file_ray(cls, i, (i >> 10) & (BHRT_ORDER_SHARDS - 1), ord, cnt);
+}
+
 // frame == nullptr: visibility goes to vis[i] (public bhrt_trace_shadow_*), else to vis[frame[i]]
 // n_dev != nullptr: the queue length is read on the device (launched ahead of the host's copy of the counters with a
 // grid sized for the upper bound n)
@@ -498,12 +551,12 @@ __global__ void __launch_bounds__(128) k_order_prefix(Counters *cnt, RayOrder or
 
 // The step's queue lengths for the host, written straight into pinned host memory (no copy engine packet, no event:
 // each of those costs the stream ~6 us of idle GPU per wave step).  The host spins on `seq` (WaitPublished).
-struct HostCounters { uint32_t n_next, n_shadow, n_frames, overflow; uint32_t pad[12]; uint32_t seq; };
+struct HostCounters { uint32_t n_next, n_shadow, n_frames, overflow, n_slow; uint32_t pad[11]; uint32_t seq; };
 __global__ void __launch_bounds__(64) k_publish(const Counters *cnt, HostCounters *pub, uint32_t seq)
 {
     if (threadIdx.x != 0) return;
     volatile HostCounters *p = pub;
-    p->n_next = cnt->n_next.v; p->n_shadow = cnt->n_shadow.v; p->n_frames = cnt->n_frames.v; p->overflow = cnt->overflow.v;
+    p->n_next = cnt->n_next.v; p->n_shadow = cnt->n_shadow.v; p->n_frames = cnt->n_frames.v; p->overflow = cnt->overflow.v; p->n_slow = cnt->n_slow.v;
     __threadfence_system();
     __hip_atomic_store(&pub->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1370,6 +1423,9 @@ struct DeviceState {
     uint32_t order_shard_cap = 0;
     uint32_t *d_seg = nullptr;                 // seg_start[97] + seg_count[96] + mesh_start[33] + mesh_count[33] + frame_base[96]
     uint32_t *d_park = nullptr;                // park_key[cap_rays] + park_sorted[cap_rays] + buckets + tile sums (RayOrder)
+    float *d_slowf = nullptr;                  // slow queue (SlowQueue): 6 * kSlowCap floats, then kSlowCap hit distances
+    uint32_t *d_slowu = nullptr;               // 3 * kSlowCap, then 3 * kSlowCap hit words (node, prim, front)
+    hipStream_t stream2 = nullptr;             // k_trace_slow runs here, beside the pass
     Counters *d_cnt = nullptr;
     HostCounters *h_pub = nullptr; // pinned, device-visible: written by k_publish
     HostCounters *d_pub = nullptr; // the device's address of h_pub
@@ -1421,12 +1477,13 @@ void DestroyDeviceState(DeviceState *d)
     fr(d->d_blob); fr(d->d_chain);
     for (int k = 0; k < 2; k++) { fr(d->d_rayf[k]); fr(d->d_rayu[k]); }
     fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_park); fr(d->d_seg); fr(d->d_cnt); fr(d->d_aux);
-    fr(d->d_frame_rgb); fr(d->d_frame_rad); fr(d->d_sel);
+    fr(d->d_frame_rgb); fr(d->d_frame_rad); fr(d->d_sel); fr(d->d_slowf); fr(d->d_slowu);
     fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_cells); fr(d->d_tile_sums);
     if (d->h_n_heavy) (void)hipHostFree(d->h_n_heavy);
     if (d->h_pub) (void)hipHostFree(d->h_pub);
     for (int k = 0; k < 2; k++) if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
     for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
+    if (d->stream2) (void)hipStreamDestroy(d->stream2);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -1781,18 +1838,53 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         int cur = 0;
         std::vector<uint32_t> frame_marks = {0};
         bool overflow = false;
-        uint64_t pass_closest = 0, pass_camera = 0, pass_shadow = 0;
+        uint64_t pass_closest = 0, pass_camera = 0, pass_shadow = 0, pass_deferred = 0;
         uint32_t pass_steps = 0; // ray counters of this pass: added to *st only when the pass completes (an overflowing pass is redone)
-        while (n_cur > 0) {
-            {
+        // rays set aside (SlowQueue): collected while the pass runs, traced and shaded in wave steps of their own once the queue is empty
+        SlowQueue slowq;
+        slowq.q = MakeRayQueue(D->d_slowf, D->d_slowu, kSlowCap);
+        slowq.cap = D->d_slowf ? kSlowCap : 0u;
+        if (getenv("BHRT_NO_SLOW_QUEUE")) slowq.cap = 0;
+        const SlowQueue no_slow = {slowq.q, 0u};
+        HitBuf slow_hits; slow_hits.t = D->d_slowf ? D->d_slowf + (size_t)6 * kSlowCap : nullptr; slow_hits.node = (int32_t *)(D->d_slowu ? D->d_slowu + (size_t)3 * kSlowCap : nullptr);
+        slow_hits.prim = slow_hits.node ? slow_hits.node + kSlowCap : nullptr; slow_hits.front = slow_hits.node ? slow_hits.node + 2 * (size_t)kSlowCap : nullptr;
+        uint32_t slow_pending = 0, slow_traced = 0; // set aside so far / of those handed to k_trace_slow
+        bool injected = false; // this wave step shades the rays that were set aside: their hits are there, and they were counted in their own step
+        if (D->stream2) HIP_CHECK(hipStreamSynchronize(D->stream2)); // nothing of an abandoned pass still reads the queue
+        while (n_cur > 0 || slow_pending > 0) {
+            injected = false;
+            if (n_cur == 0) {
+                const auto w0 = std::chrono::steady_clock::now();
+                HIP_CHECK(hipStreamSynchronize(D->stream2)); // the slow rays' hits
+                if (getenv("BHRT_DEBUG_SLOW"))
+                    fprintf(stderr, "slow rays: %u moved in after wave step %u, waited %.1f ms for their hits, pass time so far %.1f ms\n", slow_pending, pass_steps,
+                            std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() * 1e3, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3);
+                n_cur = slow_pending;
+                for (int a = 0; a < 6; a++) HIP_CHECK(hipMemcpyAsync(D->d_rayf[cur] + (size_t)a * D->cap_rays, D->d_slowf + (size_t)a * kSlowCap, (size_t)n_cur * sizeof(float), hipMemcpyDeviceToDevice, D->stream));
+                for (int a = 0; a < 3; a++) HIP_CHECK(hipMemcpyAsync(D->d_rayu[cur] + (size_t)a * D->cap_rays, D->d_slowu + (size_t)a * kSlowCap, (size_t)n_cur * sizeof(uint32_t), hipMemcpyDeviceToDevice, D->stream));
+                HIP_CHECK(hipMemcpyAsync(HB.t, slow_hits.t, (size_t)n_cur * sizeof(float), hipMemcpyDeviceToDevice, D->stream));
+                HIP_CHECK(hipMemcpyAsync(HB.node, slow_hits.node, (size_t)n_cur * sizeof(int32_t), hipMemcpyDeviceToDevice, D->stream));
+                HIP_CHECK(hipMemcpyAsync(HB.prim, slow_hits.prim, (size_t)n_cur * sizeof(int32_t), hipMemcpyDeviceToDevice, D->stream));
+                HIP_CHECK(hipMemcpyAsync(HB.front, slow_hits.front, (size_t)n_cur * sizeof(int32_t), hipMemcpyDeviceToDevice, D->stream));
+                HIP_CHECK(hipMemsetAsync(&D->d_cnt->n_slow, 0, sizeof(uint32_t), D->stream));
+                pass_deferred += n_cur;
+                slow_pending = 0; slow_traced = 0;
+                injected = true;
+            }
+            const SlowQueue &sq = slowq;
+            if (injected) {
+                Timer t(D, &st->seconds_trace_closest);
+                hipLaunchKernelGGL(k_file_all, dim3((n_cur + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, Q[cur], HB, n_cur, RO, D->d_cnt);
+                t.Stop();
+            } else {
                 Timer t(D, &st->seconds_trace_closest);
                 const dim3 tg((n_cur + kBlock - 1) / kBlock), tb(kBlock);
                 if (H->n_meshes > 0) { // park the mesh rays, then finish them in dense workgroups
                     const uint32_t n_buckets = 1u << BHRT_PARK_KEY_BITS, n_tiles = n_buckets / kScanTile;
-                    if (first_step) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<true, true>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
+                    if (first_step) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<true, true>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt, sq);
                     else {
                         HIP_CHECK(hipMemsetAsync(RO.park_bucket, 0, n_buckets * sizeof(uint32_t), D->stream)); // the trace kernel counts the keys as it parks
-                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<true, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
+                        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<true, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt, sq);
                     }
                     hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
                     if (!first_step) { // counting sort of the parked rays by coherence key (the camera step keeps slot order)
@@ -1806,8 +1898,8 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                                                   : (path_mode == 1 ? k_trace_mesh<false, 1> : path_mode == 2 ? k_trace_mesh<false, 2> : k_trace_mesh<false, 0>);
                     hipLaunchKernelGGL(mesh_kernel, first_step ? dim3(tg.x + BHRT_ORDER_SHARDS) /* shard segments padded to whole slices */ : tg, tb, 0, D->stream, D->S, P, Q[cur], HB, RO, D->d_cnt);
                     if (!first_step) hipLaunchKernelGGL(k_file_parked, dim3(tg.x + BHRT_ORDER_SHARDS), tb, 0, D->stream, Q[cur], HB, RO, D->d_cnt);
-                } else if (first_step) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, true, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, false, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt);
+                } else if (first_step) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, true, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt, no_slow);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, false, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt, no_slow);
                 t.Stop();
             }
             st->launches_trace_closest++;
@@ -1844,7 +1936,15 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 pass_closest = valid_px * (uint64_t)o.spp;
                 pass_camera = pass_closest;
                 first_step = false;
-            } else pass_closest += n_cur;
+            } else if (!injected) pass_closest += n_cur;
+            slow_pending = std::min<uint32_t>(hc.n_slow, kSlowCap);
+            if (slow_pending > slow_traced) { // the rays this step set aside: traced beside the pass
+                const uint32_t cnt_new = slow_pending - slow_traced;
+                auto slow_kernel = path_mode == 1 ? k_trace_slow<1> : path_mode == 2 ? k_trace_slow<2> : k_trace_slow<0>;
+                hipLaunchKernelGGL(slow_kernel, dim3((cnt_new + 63) / 64), dim3(64), 0, D->stream2, D->S, slowq, slow_traced, slow_pending, slow_hits);
+                if (getenv("BHRT_DEBUG_SLOW")) fprintf(stderr, "slow rays: %u set aside in wave step %u at %.1f ms\n", cnt_new, pass_steps, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3);
+                slow_traced = slow_pending;
+            }
             const uint32_t n_sh = hc.n_shadow;
             if (n_sh) { pass_shadow += n_sh; st->launches_trace_shadow++; }
             frame_marks.push_back(hc.n_frames);
@@ -1860,7 +1960,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             D->pass_hint_key = hint_key; D->pass_hint = pass_limit;
             continue;
         }
-        st->camera_samples += pass_camera; st->shadow_rays += pass_shadow; st->wave_iterations += pass_steps;
+        st->camera_samples += pass_camera; st->shadow_rays += pass_shadow; st->wave_iterations += pass_steps; st->deferred_rays += pass_deferred;
         if (o.photon_map && frame_marks.back() > 0) {
             // caustic term (MtlBlinn.cpp:329-342) of every frame of the pass in ONE gather: a gather launch lasts as long as its
             // longest query (15-80 ms for a query that fills the 1000-candidate heap), so a gather per wave step — 23 steps
@@ -1940,6 +2040,15 @@ try {
     HIP_CHECK(hipMalloc(&D->d_chain, chain.size() * sizeof(int32_t)));
     HIP_CHECK(hipMemcpy(D->d_chain, chain.data(), chain.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&D->d_cnt, sizeof(Counters)));
+    if (H->n_meshes > 0) { // SlowQueue: the rays parallel to a coordinate axis of the mesh they enter
+        HIP_CHECK(hipMalloc(&D->d_slowf, (size_t)kSlowCap * 7 * sizeof(float)));
+        HIP_CHECK(hipMalloc(&D->d_slowu, (size_t)kSlowCap * 6 * sizeof(uint32_t)));
+        {
+            int lo_prio = 0, hi_prio = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+            HIP_CHECK(hipStreamCreateWithPriority(&D->stream2, hipStreamNonBlocking, hi_prio));
+        }
+    }
     HIP_CHECK(hipMalloc(&D->d_seg, (11 * BHRT_ORDER_SHARDS + 3) * sizeof(uint32_t)));
     HIP_CHECK(hipHostMalloc(&D->h_pub, sizeof(HostCounters), hipHostMallocMapped));
     memset(D->h_pub, 0, sizeof(HostCounters));
@@ -2022,7 +2131,7 @@ try {
     RayOrder no_order = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     auto closest_kernel = scene->flat.hdr()->n_meshes > 0 ? k_trace_closest<false, false, true> : k_trace_closest<false, false, false>;
     hipLaunchKernelGGL(closest_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       scene->dev->S, PassInfo(), q, (uint32_t)n, hit_side, h, no_order, (Counters *)nullptr);
+                       scene->dev->S, PassInfo(), q, (uint32_t)n, hit_side, h, no_order, (Counters *)nullptr, SlowQueue{q, 0u});
     HIP_CHECK(hipGetLastError());
     if (!stream) HIP_CHECK(hipStreamSynchronize(s));
     return BHRT_OK;

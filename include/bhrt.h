@@ -91,6 +91,8 @@ typedef struct bhrt_stats {
     uint64_t photon_wave_queries;  /* queries whose walk was handed to a whole wave */
     uint64_t photon_exact_queries; /* heavy queries answered by the exact replay of the reference's candidate heap */
     uint64_t photon_nodes_visited; /* kd-tree nodes whose photon was examined (24 B each: SURVEY.md 8d) */
+    uint64_t deferred_rays;        /* rays parallel to a coordinate axis of the mesh they enter (Box.cpp:13-28 ignores that axis: a walk of
+                                    * nearly the whole BVH): traced in wave steps of their own at the end of their pass */
     double reserved[4];
 } bhrt_stats;
 

@@ -270,6 +270,40 @@ def test_several_mesh_nodes_park_and_resume(gpu, B, O, tmp_path):
     assert 0 <= st.closest_rays - ro["stats"].closest_rays <= ro["stats"].closest_rays // 1000
 
 
+def test_axis_parallel_rays_take_wave_steps_of_their_own(gpu, B, O, tmp_path):
+    """Box::IntersectRay leaves out an axis whose direction component is zero (Box.cpp:13-28, SURVEY.md Q15): a ray parallel to a coordinate
+    axis of a mesh's space hits every box it passes on the other axes and walks most of the BVH, in the reference and here.  The render path
+    sets such rays aside (one of them would hold up its whole wave step) and traces and shades them in wave steps of their own at the end of
+    the pass; nothing may depend on that.  A camera straight above an unrotated mesh without jitter: every ray of the image's middle column
+    and middle row has a zero component — camera rays, with their GI and shadow rays behind them.  Bit for bit against the oracle."""
+    import shutil
+    shutil.copy(os.path.join(SCENES, "mesh_small.obj"), tmp_path / "mesh_small.obj")
+    xml = tmp_path / "above.xml"
+    xml.write_text("""<xml><scene><background r="0.1" g="0.1" b="0.2"/><environment r="0.4" g="0.4" b="0.5"/>
+      <object type="plane" name="floor" material="w"><scale value="20"/></object>
+      <object type="obj" name="mesh_small.obj" material="g"><scale value="3"/><translate z="4"/></object>
+      <object type="sphere" name="s" material="r"><scale value="1.5"/><translate x="6" y="2" z="1.5"/></object>
+      <material type="blinn" name="w"><diffuse value="0.8"/><specular value="0.1"/></material>
+      <material type="blinn" name="r"><diffuse r="0.8" g="0.2" b="0.2"/><specular value="0.4"/><glossiness value="20"/></material>
+      <material type="blinn" name="g"><diffuse value="0.05"/><specular value="0.5"/><glossiness value="60"/><refraction value="0.9" index="1.5"/></material>
+      <light type="point" name="p"><intensity value="300"/><position x="3" y="-4" z="18"/><size value="1"/></light></scene>
+      <camera><position x="0" y="0" z="30"/><target x="0" y="0" z="0"/><up x="0" y="1" z="0"/><fov value="40"/><width value="64"/><height value="48"/></camera></xml>""")
+    sc = B.Scene(str(xml))
+    blob = sc.flat_bytes()
+    o, d = O.primary_rays(sc.flat_view())
+    assert ((d == 0).sum(axis=1) >= 1).sum() >= 64 + 48 - 1              # the premise: the middle column and row are axis-parallel rays
+    for spp, gi in ((2, 2), (1, 0)):
+        opts = B.default_opts(spp=spp, gi_bounces=gi, seed=6, jitter=0)
+        gs, st = sc.render_samples(opts, 0, 0, sc.width, sc.height)
+        ro = O.render(blob, sc.width, sc.height, spp, gi=gi, seed=6, jitter=0)
+        assert same_bits(gs, ro["samples"])
+        assert st.deferred_rays >= 30 * spp                              # those that enter the mesh's root box were set aside
+        assert 0 <= st.closest_rays - ro["stats"].closest_rays <= ro["stats"].closest_rays // 1000   # see test_several_mesh_nodes_park_and_resume
+    rgb, rad, st = sc.render(B.default_opts(spp=2, gi_bounces=2, seed=6, jitter=0))
+    ro = O.render(blob, sc.width, sc.height, 2, gi=2, seed=6, jitter=0, want_samples=False)
+    assert np.array_equal(rgb, ro["rgb8"]) and same_bits(rad, ro["radiance"]) and st.deferred_rays > 0
+
+
 # ---------------------------------------------------------------------------------------------------- radiance
 @pytest.mark.parametrize("case,spp,gi", [("c1_sphere_plane", 3, 3), ("c2_glass_small", 4, 3), ("c3_mesh_small", 3, 3),
                                          ("c4_textured", 3, 2), ("c2_glass_small", 2, 0), ("c2_glass_small", 2, -1),

@@ -97,6 +97,22 @@ def main():
         if group:
             n = max(out[k]["launches"] for k in group)
             per_launch["k_trace_shadow_bytes_per_launch"] = sum(out[k]["read_bytes"] + out[k]["written_bytes"] for k in group) / n
+        # the caustic gather of one pass = cell sort + lane pass + one-wave-per-query pass (+ exact replay); bench.py times it as one unit
+        group = [k for k in out if k.startswith("k_photon_gather") or k.startswith("k_gather_cell")]
+        if group:
+            n = max(1, out.get("k_photon_gather_fast", {}).get("launches", 1))
+            per_launch["k_photon_gather_bytes_per_launch"] = sum(out[k]["read_bytes"] + out[k]["written_bytes"] for k in group) / n
+        # share of its waves' resident time in which the workload's dominant kernel issues a VALU instruction, and the share of the SIMD's
+        # issue slots that is at the measured occupancy (waves per SIMD = SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / 4 SIMDs, capped at 1)
+        for k in ("k_shade", "k_trace_mesh", "k_photon_gather_fast", "k_photon_gather_select"):
+            e = out.get(k)
+            if e and e.get("SQ_WAVE_CYCLES") and e.get("SQ_BUSY_CYCLES"):
+                share = e["SQ_ACTIVE_INST_VALU"] / e["SQ_WAVE_CYCLES"]
+                waves_per_simd = e["SQ_WAVE_CYCLES"] / e["SQ_BUSY_CYCLES"] / 4.0
+                e["waves_per_simd"] = waves_per_simd
+                e["valu_issue_frac"] = min(1.0, share * waves_per_simd)
+                name = {"k_trace_mesh": "k_trace_closest", "k_photon_gather_fast": "k_photon_gather"}.get(k, k)
+                per_launch.setdefault(name + "_valu_issue_frac", e["valu_issue_frac"])
         json.dump(out, open(os.path.join(dst, f"{wl}_pmc_one_frame.json"), "w"), indent=1)
         traffic[wl] = per_launch
     traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/pmc_workload.py (one frame), "

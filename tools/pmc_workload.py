@@ -21,6 +21,9 @@ def main():
     scene_rel, W, H, spp, gi = bench.WORKLOADS[wl]
     sc = B.Scene(os.path.join(ROOT, scene_rel)); sc.upload(0)
     opts = B.default_opts(spp=spp, gi_bounces=gi, internal_bounces=16, seed=0)
+    if wl == "c5":  # BASELINE config 5: the caustic map first (its kernels appear in the counter files as well)
+        sc.photon_build(opts, 1000000)
+        opts.photon_map = 1
     rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda"); rad = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     st = sc.render_dev(opts, rgb.data_ptr(), rad.data_ptr())
     torch.cuda.synchronize()

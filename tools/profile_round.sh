@@ -7,7 +7,8 @@ TAG=${1:-r01}; WL=${2:-c2}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/trace_$WL -o $WL --output-format csv -- python3 $R/bench.py --workload $WL --no-cpu-baseline > $OUT/trace_$WL.log 2>&1
+STEPS="--steps 20 --warmup 3"; case $WL in c3|c4) STEPS="--steps 5 --warmup 1";; c3room|c5) STEPS="--steps 3 --warmup 1";; esac
+rocprofv3 --kernel-trace --stats -d $OUT/trace_$WL -o $WL --output-format csv -- python3 $R/bench.py --workload $WL --no-cpu-baseline --no-configs $STEPS > $OUT/trace_$WL.log 2>&1
 grep "^{\"metric\"" $OUT/trace_$WL.log | tail -1 > $OUT/bench_under_rocprof_$WL.json
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$WL -o p --output-format csv -- python3 $R/tools/pmc_workload.py $WL > $OUT/pmc_fetch_$WL.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_$WL -o p --output-format csv -- python3 $R/tools/pmc_workload.py $WL > $OUT/pmc_write_$WL.log 2>&1
