@@ -243,36 +243,6 @@ __device__ inline bool photon_walk_step(const PhotonMapDev &M, PhotonWalk &w, V3
     w.from = due ? cur : 0;
     return due;
 }
-// The same walk for a FIXED radius (the lane pass: no candidate heap, np.dist2[0] never shrinks): whether the far side of a node is
-// within reach can then be decided on arrival and remembered — one bit per level — instead of re-reading the node on the way back from
-// its near side.  A node is loaded twice (on arrival, and when its own photon is due after both sides) instead of up to three times.
-struct PhotonWalkFixed {
-    int cur = 1;
-    uint32_t pend = 0; // bit l: the far child of the path's node at level l is still to be walked
-    bool up = false;   // arriving from below: both sides of `cur` are done, its own photon is due
-    bool done = false;
-};
-__device__ inline bool photon_walk_step_fixed(const PhotonMapDev &M, PhotonWalkFixed &w, V3 pos, float d2max, int &node, float4 &rec)
-{
-    const int cur = w.cur;
-    const float4 h = M.hot[cur];
-    const int axis = (int)__float_as_uint(h.w);
-    const float dist = (axis == 0 ? pos.x : (axis == 1 ? pos.y : pos.z)) - (axis == 0 ? h.x : (axis == 1 ? h.y : h.z));
-    const int nearc = dist > 0 ? 2 * cur + 1 : 2 * cur;
-    const int level = 31 - __clz(cur);
-    const uint32_t bit = 1u << level, pbit = bit >> 1;
-    const bool descend = !w.up && cur < M.half;      // LocatePhotons recurses only below `half` (Q11)
-    const bool due = !descend;                       // a leaf on arrival, or both sides done
-    const bool far_ok = dist * dist < d2max;
-    const bool to_sibling = due && (w.pend & pbit) != 0; // back at the parent with its far side pending: straight to the sibling
-    node = cur;
-    rec = h;
-    w.done = due && cur == 1;
-    w.pend = descend ? (far_ok ? (w.pend | bit) : (w.pend & ~bit)) : (w.pend & ~pbit);
-    w.cur = descend ? nearc : (to_sibling ? (cur ^ 1) : (cur >> 1));
-    w.up = due && !to_sibling;
-    return due;
-}
 __device__ inline bool photon_outside_bounds(const PhotonMapDev &M, V3 pos, float radius)
 {
     const float r = radius * 1.001f + 1e-6f; // a query farther than this from the photons' box along one axis cannot accept any photon
@@ -302,11 +272,11 @@ __device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 nor
     const float d2max = radius * radius;
     int found = 0;
     V3 sumI = v3(0, 0, 0), sumD = v3(0, 0, 0);
-    PhotonWalkFixed w;
+    PhotonWalk w;
     int node;
     float4 h;
     while (!w.done) {
-        if (!photon_walk_step_fixed(M, w, pos, d2max, node, h)) continue;
+        if (!photon_walk_step(M, w, pos, d2max, node, h)) continue;
         visited++;
         if (--budget < 0) return 3;
         const float dist2 = length_sq(v3(h.x, h.y, h.z) - pos);
