@@ -348,25 +348,59 @@ __device__ inline void node_pair_at_g(const MeshRef &M, uint32_t c1, NodeRec &n1
 //     from the SECOND-visited child: return (first child's r) ? true : r
 //   children are adjacent and the first child's id is even (cyBVH.h:281-291), so sibling = id ^ 1.
 // Trail: bit (depth-1) of inFar / nearHit per level; depth <= 64 is checked at upload.
-__device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront)
+// One ray, one wave (k_trace_slow): the summaries of up to 64 subtrees that the lanes have walked side by side (mesh_closest_coop below).
+struct CoopLds {
+    uint8_t slot[2304];   // node id -> index of its summary, 0xff = none
+    uint32_t node[64];
+    uint32_t r[64];       // TraceBVHNode's return value for the subtree ...
+    float ht[64];         // ... and the hit it leaves behind when that is true
+    int32_t prim[64], front[64];
+    uint32_t n, ht_in;    // how many; bits of the HitInfo::z every one of them started from
+    uint32_t queue[128];  // scratch of the cut
+};
+// TraceBVHNode(start) — the walk below `start`, whose own box the caller has dealt with.  active = false: the lane takes no part.
+// frontier != nullptr: a node that has a summary is not walked: the summary stands in for it when the hit distance is still the one it was
+// computed from (nothing else of the state enters a subtree's decisions), else the subtree is walked now.
+template <bool kStitch = false>
+__device__ inline bool mesh_closest_from(const MeshRef &M, uint32_t start, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront, bool active = true,
+                                         CoopLds *frontier = nullptr)
 {
-    float tm;
-    const NodeRec root = node_at(M, 1);
-    int st = 3; // phase the lane waits for: 0 step down through an inner node, 1 leaf, 2 step up, 3 done
-    uint32_t data = root.data;
-    if (box_hit_rcp(root.b, o, d, ray_rcp(d), ht, tm)) st = (data & 0x80000000u) ? 1 : 0;
+    auto has_summary = [&](uint32_t id) { return kStitch && id < 2304u && frontier->slot[id] != 0xff; };
+    int st = 3; // phase the lane waits for: 0 step down through an inner node, 1 leaf, 2 step up, 3 done, 4 a node with a summary
+    uint32_t data = active ? node_data(M, start) : 0u;
+    if (active) st = has_summary(start) ? 4 : ((data & 0x80000000u) ? 1 : 0);
     const RayRcpF rf = ray_rcp_f(d);
     const float dlen = length(d);
-    uint32_t cur = 1;
+    uint32_t cur = start;
     int depth = 0;
     uint64_t inFar = 0, nearHit = 0;
     bool r = false, any = false;
     // Every round the wave runs ONE phase body, the one most of its lanes wait for (see mesh_closest_vote, which also keeps
     // the path in LDS; this form walks parent links and has no depth limit below the 64 trail bits).
     while (true) {
-        const int nD = __popcll(__ballot(st == 0)), nL = __popcll(__ballot(st == 1)), nC = __popcll(__ballot(st == 2));
-        if (nD + nL + nC == 0) break;
-        if (nD >= nL && nD >= nC) {
+        const int nD = __popcll(__ballot(st == 0)), nL = __popcll(__ballot(st == 1)), nC = __popcll(__ballot(st == 2)), nF = kStitch ? __popcll(__ballot(st == 4)) : 0;
+        if (nD + nL + nC + nF == 0) break;
+        if (kStitch && nF > 0) { // every lane is in the same state when stitching
+            if (st == 4) {
+                if (__float_as_uint(ht) != frontier->ht_in) {
+                    // a hit has moved the bound since the summaries were made: every lane walks its subtree again from the new one
+                    // (the recursion meets a handful of ever closer hits along a ray, so this happens a handful of times)
+                    const uint32_t lane = threadIdx.x & 63u, n = frontier->n;
+                    float sh = ht;
+                    int sp = hprim, sf = hfront;
+                    const bool sr = mesh_closest_from<false>(M, lane < n ? frontier->node[lane] : 1u, o, d, side, sh, sp, sf, lane < n);
+                    __syncthreads();
+                    if (lane < n) { frontier->r[lane] = sr ? 1u : 0u; frontier->ht[lane] = sh; frontier->prim[lane] = sp; frontier->front[lane] = sf; }
+                    if (lane == 0) frontier->ht_in = __float_as_uint(ht);
+                    __syncthreads();
+                }
+                const uint32_t k = frontier->slot[cur];
+                r = frontier->r[k] != 0;
+                if (r) { ht = frontier->ht[k]; hprim = frontier->prim[k]; hfront = frontier->front[k]; }
+                any |= r;
+                st = 2;
+            }
+        } else if (nD >= nL && nD >= nC) {
             if (st == 0) {
                 const uint32_t c1 = data & 0x7fffffffu;
                 float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
@@ -392,7 +426,7 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
                     nearHit &= ~bit;
                     cur = first1 ? c1 : c1 + 1;
                     data = first1 ? d1 : d2;
-                    st = (data & 0x80000000u) ? 1 : 0;
+                    st = has_summary(cur) ? 4 : ((data & 0x80000000u) ? 1 : 0);
                 }
             }
         } else if (nL >= nC) {
@@ -410,10 +444,11 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
             }
         } else {
             if (st == 2) { // one level up
-                if (depth == 0) st = 3; // the root call returned
+                if (depth == 0) st = 3; // the call on `start` returned
                 else {
                     const uint64_t bit = 1ull << (depth - 1);
                     const uint32_t sib = cur ^ 1u;
+                    const bool sib_sum = has_summary(sib);
                     if (!(inFar & bit)) {
                         if (r) {
                             nearHit |= bit;
@@ -422,13 +457,13 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
                             const uint32_t ds = ns.data;
                             int fs = rf.slow ? -1 : box_fast(ns.b, o, rf, ht, tmf);
                             if (fs < 0) fs = box_hit_rcp(ns.b, o, d, ray_rcp(d), ht, tmf) ? 1 : 0;
-                            if (fs) { inFar |= bit; cur = sib; data = ds; st = (ds & 0x80000000u) ? 1 : 0; }
+                            if (fs) { inFar |= bit; cur = sib; data = ds; st = sib_sum ? 4 : ((ds & 0x80000000u) ? 1 : 0); }
                             else { cur = node_parent(M, cur); depth--; /* r stays true */ }
                         } else {
                             inFar |= bit;
                             cur = sib;
                             data = node_data(M, sib);
-                            st = (data & 0x80000000u) ? 1 : 0;
+                            st = sib_sum ? 4 : ((data & 0x80000000u) ? 1 : 0);
                         }
                     } else {
                         r = (nearHit & bit) ? true : r;
@@ -439,6 +474,52 @@ __device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, floa
             }
         }
     }
+    return any;
+}
+// TriObj::IntersectRay (TriObj.cpp:17-39): the root box gate, then TraceBVHNode(root)
+__device__ inline bool mesh_closest(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront)
+{
+    float tm;
+    const bool enter = box_hit_rcp(node_at(M, 1).b, o, d, ray_rcp(d), ht, tm);
+    return mesh_closest_from(M, 1, o, d, side, ht, hprim, hfront, enter);
+}
+// The same for ONE ray held by all 64 lanes of a wave (k_trace_slow: a ray parallel to a coordinate axis walks up to the whole tree).
+// TraceBVHNode is a sequential recursion, but a subtree's part in it depends on the state it is entered with only through the hit
+// distance.  So: the tree's top is cut at up to 64 nodes; every lane walks the subtree of one of them from the hit distance the mesh is
+// entered with and keeps what TraceBVHNode would return (`r`) and leave behind (the hit); then the recursion is run from the root with
+// those summaries in the subtrees' place — valid as long as the hit distance is still the one they started from; when a hit has changed
+// it, the lanes walk their subtrees again from the new distance before the recursion goes on (a handful of times per ray: every time a
+// closer hit turns up).  The same boxes, triangles and comparisons in the same order as the lone walk: the same result, in a few dozen
+// parallel walks of 1/64 of the tree instead of ~10^5 dependent rounds.
+__device__ inline bool mesh_closest_coop(const MeshRef &M, CoopLds &L, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront)
+{
+    float tm;
+    if (!box_hit_rcp(node_at(M, 1).b, o, d, ray_rcp(d), ht, tm)) return false; // uniform: every lane holds the same ray
+    const uint32_t lane = threadIdx.x & 63u;
+    __syncthreads();
+    for (uint32_t k = lane; k < 2304u; k += 64) L.slot[k] = 0xff;
+    if (lane == 0) { // the cut, breadth first: inner nodes are replaced by their two children, level by level, until there are 64 nodes (or only leaves)
+        uint32_t nf = 0, head = 0, tail = 1;
+        L.queue[0] = 1;
+        while (head < tail && nf + (tail - head) < 64) {
+            const uint32_t id = L.queue[head++], dat = M.bvh[id].data, c1 = dat & 0x7fffffffu;
+            if ((dat & 0x80000000u) || c1 + 1 >= 2304u) L.node[nf++] = id;
+            else { L.queue[tail++] = c1; L.queue[tail++] = c1 + 1; }
+        }
+        while (head < tail) L.node[nf++] = L.queue[head++];
+        L.n = nf;
+        L.ht_in = __float_as_uint(ht);
+    }
+    __syncthreads();
+    const uint32_t n = L.n;
+    if (lane < n) L.slot[L.node[lane]] = (uint8_t)lane;
+    float sh = ht;
+    int sp = hprim, sf = hfront;
+    const bool sr = mesh_closest_from(M, lane < n ? L.node[lane] : 1u, o, d, side, sh, sp, sf, lane < n);
+    if (lane < n) { L.r[lane] = sr ? 1u : 0u; L.ht[lane] = sh; L.prim[lane] = sp; L.front[lane] = sf; }
+    __syncthreads();
+    const bool any = mesh_closest_from<true>(M, 1, o, d, side, ht, hprim, hfront, true, &L);
+    __syncthreads();
     return any;
 }
 
@@ -804,6 +885,25 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
         }
     }
     return parked;
+}
+
+// recursive() for ONE ray held by every lane of a wave: meshes through mesh_closest_coop (k_trace_slow)
+__device__ inline void trace_closest_coop(const DevScene &S, CoopLds &L, V3 o, V3 d, int side, Hit &h)
+{
+    h.t = BHRT_BIGFLOAT; h.node = -1; h.prim = -1; h.front = 1;
+    for (int n = 0; n < S.n_nodes; n++) {
+        const int type = S.nodes[n].obj_type;
+        if (type == BHRT_OBJ_NONE) continue;
+        V3 lp = o, ld = d;
+        local_ray(S, n, lp, ld);
+        float t;
+        int fr;
+        if (type == BHRT_OBJ_SPHERE) {
+            if (sphere_hit(lp, ld, side, h.t, t, fr)) { h.t = t; h.node = n; h.prim = -1; h.front = fr; }
+        } else if (type == BHRT_OBJ_PLANE) {
+            if (plane_hit(lp, ld, side, h.t, t, fr)) { h.t = t; h.node = n; h.prim = -1; h.front = fr; }
+        } else if (mesh_closest_coop(mesh_ref(S, S.nodes[n].mesh), L, lp, ld, side, h.t, h.prim, h.front)) h.node = n;
+    }
 }
 
 // GenLight::Shadow (GenLight.cpp:10-69).  The result is an OR over per-node tests that do not influence each

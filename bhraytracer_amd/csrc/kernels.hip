@@ -419,22 +419,27 @@ __global__ void __launch_bounds__(kBlock) k_file_parked(RayQueue q, HitBuf h, Ra
     file_ray(cls, active ? i : 0u, blockIdx.x & (BHRT_ORDER_SHARDS - 1), ord, cnt);
 }
 
-// The rays of the slow queue [a, b), traced to the end (scene graph and meshes inline) on a stream of their own while the pass goes on:
-// one wave per 64 of them — they are few, and each is a walk of up to the whole BVH.
-template <int kPath>
+// The rays of the slow queue [a, b), traced to the end on a stream of their own while the pass goes on: ONE WAVE PER RAY
+// (device_trace.h::mesh_closest_coop: the lanes walk 64 subtrees of the BVH side by side, then the recursion is put together from the
+// root) — a walk of the whole 100 k-triangle tree in ~2 ms instead of the ~100 ms a single lane needs for its 10^5 dependent rounds.
 __global__ void __launch_bounds__(64) k_trace_slow(DevScene S, SlowQueue slow, uint32_t a, uint32_t b, HitBuf h)
 {
-    typedef typename std::conditional<kPath == 2, uint32_t, uint16_t>::type PathT;
-    __shared__ PathT path[kPath ? 33 * 64 : 1];
-    __builtin_amdgcn_s_setprio(3); // one long chain of dependent steps beside a full GPU: first in line for its SIMD's issue slots
-    const uint32_t i = a + blockIdx.x * 64 + threadIdx.x;
-    const bool active = i < b;
-    V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
-    uint32_t meta = 0;
-    if (active) { o = v3(slow.q.ox[i], slow.q.oy[i], slow.q.oz[i]); d = v3(slow.q.dx[i], slow.q.dy[i], slow.q.dz[i]); meta = slow.q.meta[i]; }
+    __shared__ CoopLds lds;
+    __builtin_amdgcn_s_setprio(3); // a chain of dependent steps beside a full GPU: first in line for its SIMD's issue slots
+    const uint32_t i = a + blockIdx.x;
+    if (i >= b) return; // uniform
+    const V3 o = v3(slow.q.ox[i], slow.q.oy[i], slow.q.oz[i]), d = v3(slow.q.dx[i], slow.q.dy[i], slow.q.dz[i]);
+    const uint32_t meta = slow.q.meta[i];
     Hit hit;
-    trace_closest<true, PathT>(S, o, d, (int)((meta >> 4) & 3u), hit, active, nullptr, 0, false, nullptr, kPath ? path + threadIdx.x : (PathT *)nullptr, 64, 0);
-    if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; }
+#ifdef BHRT_DEBUG_LONG_RAYS
+    const unsigned long long c0 = wall_clock64();
+#endif
+    trace_closest_coop(S, lds, o, d, (int)((meta >> 4) & 3u), hit);
+#ifdef BHRT_DEBUG_LONG_RAYS
+    const double ms = (double)(wall_clock64() - c0) / 1e5; // 100 MHz
+    if (threadIdx.x == 0 && ms > 5.0) printf("slow ray %u: %.1f ms o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) side %u -> node %d prim %d t %.9g\n", i, ms, o.x, o.y, o.z, d.x, d.y, d.z, (meta >> 4) & 3u, hit.node, hit.prim, hit.t);
+#endif
+    if (threadIdx.x == 0) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; }
 }
 // Files rays whose hits are already there (the slow queue, moved into the ray queue) for shading.
 __global__ void __launch_bounds__(kBlock) k_file_all(RayQueue q, HitBuf h, uint32_t n, RayOrder ord, Counters *cnt)
@@ -1940,8 +1945,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             slow_pending = std::min<uint32_t>(hc.n_slow, kSlowCap);
             if (slow_pending > slow_traced) { // the rays this step set aside: traced beside the pass
                 const uint32_t cnt_new = slow_pending - slow_traced;
-                auto slow_kernel = path_mode == 1 ? k_trace_slow<1> : path_mode == 2 ? k_trace_slow<2> : k_trace_slow<0>;
-                hipLaunchKernelGGL(slow_kernel, dim3((cnt_new + 63) / 64), dim3(64), 0, D->stream2, D->S, slowq, slow_traced, slow_pending, slow_hits);
+                hipLaunchKernelGGL(k_trace_slow, dim3(cnt_new), dim3(64), 0, D->stream2, D->S, slowq, slow_traced, slow_pending, slow_hits);
                 if (getenv("BHRT_DEBUG_SLOW")) fprintf(stderr, "slow rays: %u set aside in wave step %u at %.1f ms\n", cnt_new, pass_steps, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3);
                 slow_traced = slow_pending;
             }
