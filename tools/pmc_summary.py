@@ -102,16 +102,27 @@ def main():
         if group:
             n = max(1, out.get("k_photon_gather_fast", {}).get("launches", 1))
             per_launch["k_photon_gather_bytes_per_launch"] = sum(out[k]["read_bytes"] + out[k]["written_bytes"] for k in group) / n
-        # share of its waves' resident time in which the workload's dominant kernel issues a VALU instruction, and the share of the SIMD's
-        # issue slots that is at the measured occupancy (waves per SIMD = SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / 4 SIMDs, capped at 1)
-        for k in ("k_shade", "k_trace_mesh", "k_photon_gather_fast", "k_photon_gather_select"):
+        # VALU issue fraction of the workload's heavy kernels: wave-level VALU instructions of ONE frame (SQ_INSTS_VALU, PMC pass) x 4 cycles
+        # (a wave64 instruction occupies its SIMD's 16 lanes for 4 cycles; measured 3.1-4.6 for this path's mix) over the
+        # SIMD-cycles the kernel had: 1024 SIMDs x its time per frame (kernel-trace run of the same workload) x 2.4 GHz
+        frames = None
+        try:
+            bj2 = json.load(open(os.path.join(dst, f"{wl}_bench_under_rocprof.json")))
+            frames = bj2["steps"] + bj2["warmup"] + 1  # + the untimed first frame
+        except Exception:
+            pass
+        ktime = collections.defaultdict(float)
+        sp = os.path.join(dst, f"{wl}_kernel_stats.csv")
+        if os.path.exists(sp):
+            for r in csv.DictReader(open(sp)):
+                ktime[short(r["Name"])] += float(r["TotalDurationNs"]) * 1e-9
+        for k in ("k_shade", "k_trace_mesh", "k_shadow_mesh", "k_photon_gather_fast", "k_photon_gather_select"):
             e = out.get(k)
-            if e and e.get("SQ_WAVE_CYCLES") and e.get("SQ_BUSY_CYCLES"):
-                share = e["SQ_ACTIVE_INST_VALU"] / e["SQ_WAVE_CYCLES"]
-                waves_per_simd = e["SQ_WAVE_CYCLES"] / e["SQ_BUSY_CYCLES"] / 4.0
-                e["waves_per_simd"] = waves_per_simd
-                e["valu_issue_frac"] = min(1.0, share * waves_per_simd)
-                name = {"k_trace_mesh": "k_trace_closest", "k_photon_gather_fast": "k_photon_gather"}.get(k, k)
+            if e and frames and ktime.get(k) and e.get("SQ_INSTS_VALU"):
+                sec = ktime[k] / frames
+                e["seconds_per_frame"] = sec
+                e["valu_issue_frac"] = e["SQ_INSTS_VALU"] * 4.0 / (1024 * sec * 2.4e9)
+                name = {"k_trace_mesh": "k_trace_closest", "k_shadow_mesh": "k_trace_shadow", "k_photon_gather_fast": "k_photon_gather"}.get(k, k)
                 per_launch.setdefault(name + "_valu_issue_frac", e["valu_issue_frac"])
         json.dump(out, open(os.path.join(dst, f"{wl}_pmc_one_frame.json"), "w"), indent=1)
         traffic[wl] = per_launch
