@@ -58,3 +58,26 @@ def test_pack_unpack_roundtrip_any_world():
             assert torch.equal(BD.unpack_tiles(torch.stack(packs), W, H, tile), img)
             masks = torch.stack([BD.owned_mask(W, H, tile, r, world) for r in range(world)])
             assert torch.equal(masks.sum(0), torch.ones(H, W, dtype=torch.int64))
+
+
+def test_bench_never_falls_through_to_one_gpu():
+    """`bench.py --gpus N` must run N ranks or fail: with a torchrun environment of another size it refuses (exit code != 0) instead of
+    benchmarking a different world; without one it starts the ranks itself (covered on the GPU box by the test below)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` outside torchrun: two ranks are started (here both on the one GPU of the box, exchange through gloo:
+    --rehearse-on-one-gpu), the JSON line reports n_gpus = 2 and the spp of two ranks."""
+    import json, subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--workload", "c1", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "2 spp (1 per GPU)" in d["config"]["workload"] and d["value"] > 0
