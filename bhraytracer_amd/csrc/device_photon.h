@@ -210,6 +210,8 @@ __device__ inline uint32_t emit_photon_path(const DevScene &S, uint32_t seed, ui
 struct PhotonMapDev {
     const float4 *hot;  // [n+1]: pos.xyz, w = bits of (planeAndDirZ & 3)
     const float4 *cold; // [2*(n+1)]: {dir.xyz, power}, {power * color.rgb, 0}
+    const float4 *dbox; // [2*n_dbox]: {lo.xyz}, {hi.xyz}: bounds of the DIRECTIONS of the photons LocatePhotons reaches below node i (itself included), for the tree's top levels
+    int n_dbox;         // nodes [1, n_dbox) have one (BHRT_DBOX_LEVELS levels)
     int n, half;        // photons[1..n] in heap order; half = n/2 - 1 (cyPhotonMap.h:257)
     float lo[3], hi[3]; // bounds of the photon positions
 };
@@ -340,6 +342,20 @@ __device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 nor
 // well — 40 KB — a CU held four waves and the pass ran at a sixth of the lane pass's rate per node).  The candidates live in a scratch
 // of the wave in global memory: appended with coalesced stores, read back into registers — lane l holds entries l, l + 64, ... — when the
 // buffer is full, where the selection runs on registers only.
+// LocatePhotons drops a photon whose direction has a non-negative dot product with the query's normal (cyPhotonMap.h:443-446).  With the
+// bounds of the directions below a node, min over the box of d . n = sum_i min(lo_i n_i, hi_i n_i) is a lower bound of every such product;
+// when it is clearly positive (2^-20 |n|_1: the products are sums of three terms of magnitude <= |n_i| with a rounding error below
+// 2^-22 |n|_1 each way) every photon below the node is dropped by that test and the node's subtree holds nothing for this query —
+// whatever its distance.  A point on the glass sphere right above the caustic has 4 * 10^5 photons in reach, all of them travelling
+// the wrong way: the long walks of the gather were walks through such subtrees.
+#define BHRT_DBOX_LEVELS 16
+__device__ inline bool photon_subtree_rejected(const PhotonMapDev &M, uint32_t node, V3 n)
+{
+    if ((int)node >= M.n_dbox) return false;
+    const float4 lo = M.dbox[2 * (size_t)node], hi = M.dbox[2 * (size_t)node + 1];
+    const float bound = fminf(lo.x * n.x, hi.x * n.x) + fminf(lo.y * n.y, hi.y * n.y) + fminf(lo.z * n.z, hi.z * n.z);
+    return bound >= 9.5367431640625e-07f * (fabsf(n.x) + fabsf(n.y) + fabsf(n.z)); // 2^-20; NaN compares false
+}
 struct SelectLds {
     uint32_t st_node[BHRT_SEL_STACK], st_sides[BHRT_SEL_STACK];
     float st_plane[BHRT_SEL_STACK]; // squared distance to the splitting plane that justified a far-side entry (0 for near-side entries)
@@ -473,6 +489,7 @@ __device__ inline int photon_estimate_select(const PhotonMapDev &M, SelectLds &L
             valid[u] = e < base + take && L.st_plane[e] < bound; // a far side entered under a looser bound may be out of reach by now
             node[u] = valid[u] ? L.st_node[e] : 1u;
             sides[u] = valid[u] ? L.st_sides[e] : 0u;
+            if (valid[u] && photon_subtree_rejected(M, node[u], normal)) valid[u] = false; // nothing below it passes the normal test
         }
         __syncthreads(); // every lane has read its stack slots
 #pragma unroll

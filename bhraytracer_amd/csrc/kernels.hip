@@ -1456,7 +1456,7 @@ struct DeviceState {
     std::vector<HostPhoton> h_photons; // balanced copy for bhrt_photon_export
     float *d_ph_frames = nullptr;      // 15 * cap_frames floats (p, N, V, kd, ks per frame), only with photon_map
     uint32_t ph_frames_cap = 0;
-    float4 *d_ph_hot = nullptr, *d_ph_cold = nullptr; // decoded copy the gather walks (PhotonMapDev)
+    float4 *d_ph_hot = nullptr, *d_ph_cold = nullptr, *d_ph_dbox = nullptr; // decoded copy the gather walks (PhotonMapDev)
     PhotonMapDev pm;
     unsigned long long *d_scr = nullptr; // candidate heaps of the heavy queries: (K+1) x scr_lanes, element-major
     uint32_t scr_lanes = 0;
@@ -1488,7 +1488,7 @@ void DestroyDeviceState(DeviceState *d)
     for (int k = 0; k < 2; k++) { fr(d->d_rayf[k]); fr(d->d_rayu[k]); }
     fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_park); fr(d->d_seg); fr(d->d_cnt); fr(d->d_aux);
     fr(d->d_frame_rgb); fr(d->d_frame_rad); fr(d->d_sel); fr(d->d_slowf); fr(d->d_slowu);
-    fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_cells); fr(d->d_tile_sums);
+    fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_ph_dbox); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_cells); fr(d->d_tile_sums);
     if (d->h_n_heavy) (void)hipHostFree(d->h_n_heavy);
     if (d->h_pub) (void)hipHostFree(d->h_pub);
     for (int k = 0; k < 2; k++) if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
@@ -2424,6 +2424,31 @@ static int InstallPhotonMap(DeviceState *D)
     hipLaunchKernelGGL(k_photon_expand, dim3((n + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->d_photons, n, D->d_ph_hot, D->d_ph_cold);
     HIP_CHECK(hipStreamSynchronize(D->stream));
     D->pm.hot = D->d_ph_hot; D->pm.cold = D->d_ph_cold; D->pm.n = (int)n; D->pm.half = (int)n / 2 - 1;
+    { // PhotonMapDev::dbox: bounds of the directions of the photons LocatePhotons reaches below every node (it recurses only below `half`), bottom up
+        std::vector<float> lo(((size_t)n + 1) * 3), hi(((size_t)n + 1) * 3);
+        const int half = D->pm.half;
+        for (size_t i = n; i >= 1; i--) {
+            DPhoton p;
+            memcpy(&p, &D->h_photons[i], sizeof p);
+            const V3 d = photon_direction(p); // the arithmetic k_photon_expand uses (IEEE divisions, integer square root)
+            float l3[3] = {d.x, d.y, d.z}, h3[3] = {d.x, d.y, d.z};
+            if ((int)i < half)
+                for (size_t c = 2 * i; c <= 2 * i + 1 && c <= n; c++)
+                    for (int k = 0; k < 3; k++) { l3[k] = std::min(l3[k], lo[c * 3 + k]); h3[k] = std::max(h3[k], hi[c * 3 + k]); }
+            for (int k = 0; k < 3; k++) { lo[i * 3 + k] = l3[k]; hi[i * 3 + k] = h3[k]; }
+        }
+        const uint32_t nb = std::min<uint32_t>(n + 1, 1u << BHRT_DBOX_LEVELS);
+        std::vector<float4> box((size_t)nb * 2, make_float4(0, 0, 0, 0));
+        for (uint32_t i = 1; i < nb; i++) {
+            box[2 * (size_t)i] = make_float4(lo[(size_t)i * 3], lo[(size_t)i * 3 + 1], lo[(size_t)i * 3 + 2], 0.f);
+            box[2 * (size_t)i + 1] = make_float4(hi[(size_t)i * 3], hi[(size_t)i * 3 + 1], hi[(size_t)i * 3 + 2], 0.f);
+        }
+        if (D->d_ph_dbox) (void)hipFree(D->d_ph_dbox);
+        D->d_ph_dbox = nullptr;
+        HIP_CHECK(hipMalloc(&D->d_ph_dbox, box.size() * sizeof(float4)));
+        HIP_CHECK(hipMemcpy(D->d_ph_dbox, box.data(), box.size() * sizeof(float4), hipMemcpyHostToDevice));
+        D->pm.dbox = D->d_ph_dbox; D->pm.n_dbox = (int)nb;
+    }
     for (int k = 0; k < 3; k++) { D->pm.lo[k] = BHRT_BIGFLOAT; D->pm.hi[k] = -BHRT_BIGFLOAT; }
     for (size_t i = 1; i <= n; i++)
         for (int k = 0; k < 3; k++) {
