@@ -302,10 +302,11 @@ def main():
     if N > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
         if args.rehearse_on_one_gpu:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=5))
+        else:  # a rank that dies must not leave the others waiting in a collective for RCCL's default half hour
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(minutes=5))
     if rank == 0:
         ensure_assets()
     if N > 1:

@@ -328,3 +328,59 @@ def test_gpu_photon_records_stay_on_the_device(B, load_scene):
     assert sc.photon_install_ptr(rec.data_ptr(), N) == N and np.array_equal(sc.photon_get(), single)
     assert BD.photon_build_sharded(sc, opts, N, 0, 1, device=dev) == N and np.array_equal(sc.photon_get(), single)
     assert BD.photon_build_sharded(sc, opts, N, 0, 1, device=None, batch=1 << 18) == N and np.array_equal(sc.photon_get(), single)
+
+
+def test_the_list_locate_photons_ends_with_is_a_set_rule(O):
+    """What the HIP path's selection pass relies on (device_photon.h): with A = the acceptable photons inside the radius in walk order, F its
+    first 1000 and m the farthest of F, LocatePhotons ends with the 1000 nearest of A - {m} (the 1001st photon replaces the heap's root
+    unconditionally, np.dist2[0] is still r^2 then; from there on it is a streaming selection), and np.dist2[0] = their largest distance.
+    Checked here on the CPU against the oracle's faithful replay of the heap (itself pinned to the reference): a Python walk of the
+    balanced map gives A in walk order, numpy applies the rule."""
+    rng = np.random.RandomState(11)
+    n = 9000
+    rec = np.zeros((n, 24), np.uint8)
+    pos = rng.uniform([-1.2, -1.2, 0], [1.2, 1.2, 0.3], (n, 3)).astype(np.float32)
+    rec[:, 0:12] = pos.view(np.uint8).reshape(n, 12)
+    rec[:, 12:16] = np.frombuffer(np.float32(1.0 / n).tobytes(), np.uint8)
+    rec[:, 16:19] = 255
+    rec[:, 19] = 0x8          # dirX = dirY = 0, dirZ < 0: direction (0, 0, -1), accepted by every query with normal (0, 0, 1)
+    bal = O.photon_balance(rec)
+    O.photon_attach(bal)
+    P = bal[:, 0:12].copy().view(np.float32).reshape(n, 3)
+    axis = bal[:, 19] & 3
+    half = n // 2 - 1
+    r2 = np.float32(0.5) * np.float32(0.5)
+
+    def d2_of(i, q):  # photon i (1-based), float32 like Vec3f::LengthSquared
+        d = (P[i - 1] - q).astype(np.float32)
+        return np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+
+    def walk(i, q, out):  # LocatePhotons' order with the radius fixed at r (what holds until the 1001st photon)
+        if i < half:
+            dist = np.float32(q[axis[i - 1]] - P[i - 1][axis[i - 1]])
+            near, far = (2 * i + 1, 2 * i) if dist > 0 else (2 * i, 2 * i + 1)
+            walk(near, q, out)
+            if np.float32(dist * dist) < r2:
+                walk(far, q, out)
+        if d2_of(i, q) < r2:
+            out.append(i)
+
+    q = np.concatenate([rng.uniform([-0.9, -0.9, 0.0], [0.9, 0.9, 0.0], (40, 3)), rng.uniform([-1.6, -1.6, 0.0], [1.6, 1.6, 0.0], (20, 3))]).astype(np.float32)
+    nrm = np.tile(np.float32([0, 0, 1]), (len(q), 1))
+    idx, cnt, d2max = O.photon_knn(q, nrm, 0.5)
+    heavy = 0
+    for k in range(len(q)):
+        A = []
+        walk(1, q[k], A)
+        dist = {i: d2_of(i, q[k]) for i in A}
+        if len(A) <= 1000:
+            expect, bound = sorted(A), r2
+        else:
+            heavy += 1
+            F = A[:1000]
+            m = max(F, key=lambda i: dist[i])
+            rest = sorted((i for i in A if i != m), key=lambda i: dist[i])[:1000]
+            expect, bound = sorted(rest), max(dist[i] for i in rest)
+        assert cnt[k] == len(expect) and np.array_equal(np.sort(idx[k][:cnt[k]]), np.uint32(expect)), k
+        assert np.float32(d2max[k]) == np.float32(bound), k
+    assert heavy >= 20
