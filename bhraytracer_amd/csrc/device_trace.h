@@ -208,20 +208,29 @@ __device__ inline bool tri_areas(const bhrt_tri &tr, V3 vX, float &a0, float &a1
     return true;
 }
 
-// TriObj::IntersectTriangle (TriObj.cpp:68-189) up to the accept decision; dlen = ray.dir.Length();
-// vN, |vN| and vN.v0 come precomputed with the triangle (same float operations as TriObj.cpp:79,85,89)
-__device__ inline bool tri_hit(const bhrt_tri &tr, V3 o, V3 d, float dlen, int side, float t_cur, float &t_out, int &front_out)
+// TriObj::IntersectTriangle (TriObj.cpp:68-189) up to the accept decision, in two parts: the plane part (TriObj.cpp:79-103: needs the first
+// 20 bytes of the record) and the barycentric part (the rest of the record, read only when the plane hit lies in range).
+// vN, |vN| and vN.v0 come precomputed with the triangle (same float operations as TriObj.cpp:79,85,89); dlen = ray.dir.Length().
+struct TriPlane { float nx, ny, nz, nd, len; };
+__device__ inline TriPlane tri_plane_ld(const bhrt_tri *tr)
+{
+    const float4 a = *(const float4 *)tr->vN; // vN, vN_dot_v0: one 16-byte load
+    TriPlane P;
+    P.nx = a.x; P.ny = a.y; P.nz = a.z; P.nd = a.w; P.len = tr->vN_len;
+    return P;
+}
+__device__ inline bool tri_plane_test(const TriPlane &P, V3 o, V3 d, float dlen, int side, float t_cur, float &t, bool &hitFront)
 {
     // The reference returns at each failed test; here the cheap tests are evaluated straight through and AND-ed (a wave
     // of 64 rays almost always has a lane that passes each of them, so the early returns only cost branches), with one
     // branch left in front of the barycentric part.  Divisions by zero only feed predicates that are already false.
-    V3 vN = ld3(tr.vN);
-    float t_divisor = dot(vN, d);
+    const V3 vN = v3(P.nx, P.ny, P.nz);
+    const float t_divisor = dot(vN, d);
     bool ok = t_divisor != 0;
     // grazing test `abs(t_divisor / (|vN| * |d|)) < 0.001745` (TriObj.cpp:85-88): the quotient is only compared, so an
     // approximate one (hardware reciprocal: within 2^-21 of the rounded quotient) decides unless it lies within 2^-19 of the
     // threshold; a zero or subnormal denominator gives an infinite approximation = "not grazing", like the division does
-    const float den = tr.vN_len * dlen;
+    const float den = P.len * dlen;
     const float aperp = fabsf(t_divisor * __builtin_amdgcn_rcpf(den));
     bool grazing = aperp < BHRT_PERP;
     if (fabsf(aperp - BHRT_PERP) <= BHRT_PERP * BHRT_FAST_REL || aperp != aperp) {
@@ -229,17 +238,59 @@ __device__ inline bool tri_hit(const bhrt_tri &tr, V3 o, V3 d, float dlen, int s
         grazing = perp > -BHRT_PERP && perp < BHRT_PERP;
     }
     ok = ok && !grazing;
-    float t = (tr.vN_dot_v0 - dot(vN, o)) / t_divisor;
+    t = (P.nd - dot(vN, o)) / t_divisor;
     ok = ok && !(t <= 0 || t > t_cur);
-    bool hitFront = t_divisor < 0;
-    ok = ok && !(!hitFront && side == BHRT_HIT_FRONT) && !(hitFront && side == BHRT_HIT_BACK);
-    if (!ok) return false;
+    hitFront = t_divisor < 0;
+    return ok && !(!hitFront && side == BHRT_HIT_FRONT) && !(hitFront && side == BHRT_HIT_BACK);
+}
+__device__ inline bool tri_hit(const bhrt_tri &tr, V3 o, V3 d, float dlen, int side, float t_cur, float &t_out, int &front_out)
+{
+    float t;
+    bool hitFront;
+    if (!tri_plane_test(tri_plane_ld(&tr), o, d, dlen, side, t_cur, t, hitFront)) return false;
     V3 vX = o + t * d;
     float a0, a1, a2;
     if (!tri_areas(tr, vX, a0, a1, a2)) return false;
     t_out = t;
     front_out = hitFront ? 1 : 0;
     return true;
+}
+// The triangles [off, off + count) of a leaf in order (TriObj.cpp:231-246: every hit lowers the bound the next triangle is tested against).
+// The plane parts of four triangles are fetched TOGETHER: fetched one by one inside the loop, every triangle costs the wave two to three
+// memory round trips in a row (plane part, then the vertices) — a leaf of four was 8-12 dependent waits long, the longest chain of a round.
+#ifndef BHRT_LEAF_BATCH
+#define BHRT_LEAF_BATCH 1
+#endif
+__device__ inline bool leaf_hits(const bhrt_tri *tris, uint32_t off, uint32_t count, V3 o, V3 d, float dlen, int side, float &ht, int &hprim, int &hfront)
+{
+    bool r = false;
+#if BHRT_LEAF_BATCH
+    for (uint32_t base = 0; base < count; base += 4) { // a leaf holds at most 8
+        TriPlane P[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) P[k] = tri_plane_ld(tris + off + min(base + k, count - 1)); // past the end: the last one again (not tested)
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            if (base + k < count) {
+                const bhrt_tri &tr = tris[off + base + k];
+                float t;
+                bool hitFront;
+                if (tri_plane_test(P[k], o, d, dlen, side, ht, t, hitFront)) {
+                    float a0, a1, a2;
+                    if (tri_areas(tr, o + t * d, a0, a1, a2)) { ht = t; hprim = (int)(tr.face_axis & 0x3fffffffu); hfront = hitFront ? 1 : 0; r = true; }
+                }
+            }
+        }
+    }
+#else
+    for (uint32_t i = 0; i < count; i++) {
+        const bhrt_tri &tr = tris[off + i];
+        float t;
+        int fr;
+        if (tri_hit(tr, o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)(tr.face_axis & 0x3fffffffu); hfront = fr; r = true; }
+    }
+#endif
+    return r;
 }
 
 struct MeshRef {
@@ -432,13 +483,7 @@ __device__ inline bool mesh_closest_from(const MeshRef &M, uint32_t start, V3 o,
         } else if (nL >= nC) {
             if (st == 1) {
                 const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
-                r = false;
-                for (uint32_t i = 0; i < count; i++) {
-                    const bhrt_tri &tr = M.ltris[off + i];
-                    float t;
-                    int fr;
-                    if (tri_hit(tr, o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)(tr.face_axis & 0x3fffffffu); hfront = fr; r = true; }
-                }
+                r = leaf_hits(M.ltris, off, count, o, d, dlen, side, ht, hprim, hfront);
                 any |= r;
                 st = 2;
             }
@@ -530,110 +575,137 @@ __device__ inline bool mesh_closest_coop(const MeshRef &M, CoopLds &L, V3 o, V3 
 // ... and with the wave running, in every round, the ONE phase most of its lanes wait for (descend step / leaf /
 // climb step: a wave-uniform choice from three ballots) instead of the three phase loops in turn, each until its last lane
 // is through: same per-ray operation sequence, ~1.2x the lanes per instruction (C3 trace 61 -> 51 ms).
-template <class PathT> // uint16_t (pair indices < 2^16: meshes below 2^17 nodes) or uint32_t
-__device__ inline bool mesh_closest_vote(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront, PathT *stack, uint32_t stride)
+#ifndef BHRT_FUSED_CLIMB
+#define BHRT_FUSED_CLIMB 1
+#endif
+#ifndef BHRT_VOTE_D
+#define BHRT_VOTE_D 1 /* the round is a descend step when lanes waiting for one x BHRT_VOTE_D >= lanes waiting for a leaf x BHRT_VOTE_L */
+#define BHRT_VOTE_L 1
+#endif
+// One lane's walk, cut into rounds so that a wave can take new rays in between (kernels.hip::k_trace_mesh_stream): the state a round
+// reads and writes.  st: 0 descend step, 1 leaf, 2 climb step, 3 done.
+struct MeshWalk {
+    V3 o, d; // the ray in the mesh's space
+    RayRcpF rf;
+    float dlen;
+    uint32_t data, inFar, nearHit, sides;
+    int depth, st;
+    bool r, any;
+};
+// the root box gate of TriObj::IntersectRay (TriObj.cpp:17-39)
+__device__ inline void walk_begin(const MeshRef &M, MeshWalk &W, V3 o, V3 d, float ht)
 {
     float tm;
     const NodeRec root = node_at_g(M, 1);
-    int st = 3; // 0 descend step, 1 leaf, 2 climb step, 3 done
-    uint32_t data = root.data;
-    if (box_hit_rcp(root.b, o, d, ray_rcp(d), ht, tm)) st = (data & 0x80000000u) ? 1 : 0;
-    const RayRcpF rf = ray_rcp_f(d);
-    const float dlen = length(d);
-    uint32_t cur = 1;
-    int depth = 0;
-    uint32_t inFar = 0, nearHit = 0, sides = 0;
-    bool r = false, any = false;
-#ifdef BHRT_DEBUG_LONG_RAYS
-    uint32_t dbg_round = 0, dbg_mine = 0, dbg_desc = 0, dbg_leaf = 0;
+    W.o = o; W.d = d;
+    W.st = 3;
+    W.data = root.data;
+    if (box_hit_rcp(root.b, o, d, ray_rcp(d), ht, tm)) W.st = (W.data & 0x80000000u) ? 1 : 0;
+    W.rf = ray_rcp_f(d);
+    W.dlen = length(d);
+    W.depth = 0;
+    W.inFar = 0; W.nearHit = 0; W.sides = 0;
+    W.r = false; W.any = false;
+}
+// One round: the wave runs the phase most of its lanes wait for (nD / nL / nC = lanes waiting for a descend step / a leaf / a climb step).
+template <class PathT> // uint16_t (pair indices < 2^16: meshes below 2^17 nodes) or uint32_t
+__device__ inline void walk_round(const MeshRef &M, MeshWalk &W, int side, float &ht, int &hprim, int &hfront, PathT *stack, uint32_t stride, int nD, int nL, int nC)
+{
+    const V3 o = W.o, d = W.d;
+#if BHRT_FUSED_CLIMB
+    // the climb step rides at the end of EVERY round (lanes that have just left a leaf or missed both boxes included): a lane never waits for a
+    // round of its own to climb, and the vote is between two phases
+    if (nD * BHRT_VOTE_D >= nL * BHRT_VOTE_L && nD > 0) {
+#else
+    if (nD >= nL && nD >= nC) {
 #endif
-    while (true) {
-        const int nD = __popcll(__ballot(st == 0)), nL = __popcll(__ballot(st == 1)), nC = __popcll(__ballot(st == 2));
-        if (nD + nL + nC == 0) break;
-#ifdef BHRT_DEBUG_LONG_RAYS
-        dbg_round++;
-        if (st != 3) dbg_mine = dbg_round;
-        if (nD >= nL && nD >= nC) { if (st == 0) dbg_desc++; } else if (nL >= nC) { if (st == 1) dbg_leaf++; }
+        if (W.st == 0) {
+            const uint32_t c1 = W.data & 0x7fffffffu;
+            float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
+            NodeRec n1, n2;
+            node_pair_at_g(M, c1, n1, n2);
+            const uint32_t d1 = n1.data, d2 = n2.data;
+            const int f1 = W.rf.slow ? -1 : box_fast(n1.b, o, W.rf, ht, tmin1), f2 = W.rf.slow ? -1 : box_fast(n2.b, o, W.rf, ht, tmin2);
+            bool b1 = f1 == 1, b2 = f2 == 1;
+            int ord = (b1 && b2) ? order_fast(tmin1, tmin2) : (b1 ? 1 : 0);
+            if (f1 < 0 || f2 < 0 || ord < 0) {
+                const RayRcp rr = ray_rcp(d);
+                tmin1 = BHRT_BIGFLOAT; tmin2 = BHRT_BIGFLOAT;
+                b1 = box_hit_rcp(n1.b, o, d, rr, ht, tmin1);
+                b2 = box_hit_rcp(n2.b, o, d, rr, ht, tmin2);
+                ord = tmin1 < tmin2 ? 1 : 0;
+            }
+            if (!b1 && !b2) { W.r = false; W.st = 2; }
+            else {
+                W.depth++;
+                const uint32_t bit = 1u << (W.depth - 1);
+                const bool first1 = ord == 1;
+                W.inFar = skip_missed(M, first1 ? b2 : b1, first1 ? d2 : d1) ? (W.inFar | bit) : (W.inFar & ~bit);
+                W.nearHit &= ~bit;
+                W.data = first1 ? d1 : d2;
+                W.sides = first1 ? (W.sides & ~bit) : (W.sides | bit);
+                stack[(uint32_t)W.depth * stride] = (PathT)(c1 >> 1);
+                W.st = (W.data & 0x80000000u) ? 1 : 0;
+            }
+        }
+#if BHRT_FUSED_CLIMB
+    } else if (nL > 0) {
+#else
+    } else if (nL >= nC) {
 #endif
-        if (nD >= nL && nD >= nC) {
-            if (st == 0) {
-                const uint32_t c1 = data & 0x7fffffffu;
-                float tmin1 = BHRT_BIGFLOAT, tmin2 = BHRT_BIGFLOAT;
-                NodeRec n1, n2;
-                node_pair_at_g(M, c1, n1, n2);
-                const uint32_t d1 = n1.data, d2 = n2.data;
-                const int f1 = rf.slow ? -1 : box_fast(n1.b, o, rf, ht, tmin1), f2 = rf.slow ? -1 : box_fast(n2.b, o, rf, ht, tmin2);
-                bool b1 = f1 == 1, b2 = f2 == 1;
-                int ord = (b1 && b2) ? order_fast(tmin1, tmin2) : (b1 ? 1 : 0);
-                if (f1 < 0 || f2 < 0 || ord < 0) {
-                    const RayRcp rr = ray_rcp(d);
-                    tmin1 = BHRT_BIGFLOAT; tmin2 = BHRT_BIGFLOAT;
-                    b1 = box_hit_rcp(n1.b, o, d, rr, ht, tmin1);
-                    b2 = box_hit_rcp(n2.b, o, d, rr, ht, tmin2);
-                    ord = tmin1 < tmin2 ? 1 : 0;
-                }
-                if (!b1 && !b2) { r = false; st = 2; }
-                else {
-                    depth++;
-                    const uint32_t bit = 1u << (depth - 1);
-                    const bool first1 = ord == 1;
-                    inFar = skip_missed(M, first1 ? b2 : b1, first1 ? d2 : d1) ? (inFar | bit) : (inFar & ~bit);
-                    nearHit &= ~bit;
-                    cur = first1 ? c1 : c1 + 1;
-                    data = first1 ? d1 : d2;
-                    sides = first1 ? (sides & ~bit) : (sides | bit);
-                    stack[(uint32_t)depth * stride] = (PathT)(c1 >> 1);
-                    st = (data & 0x80000000u) ? 1 : 0;
-                }
-            }
-        } else if (nL >= nC) {
-            if (st == 1) {
-                const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
-                r = false;
-                for (uint32_t i = 0; i < count; i++) {
-                    const bhrt_tri &tr = M.ltris[off + i];
-                    float t;
-                    int fr;
-                    if (tri_hit(tr, o, d, dlen, side, ht, t, fr)) { ht = t; hprim = (int)(tr.face_axis & 0x3fffffffu); hfront = fr; r = true; }
-                }
-                any |= r;
-                st = 2;
-            }
-        } else {
-            if (st == 2) {
-                const uint32_t below = depth >= 32 ? 0xffffffffu : (depth > 0 ? ((1u << depth) - 1u) : 0u);
-                const uint32_t waiting = ~inFar & below;
-                if (!waiting) { depth = 0; st = 3; }
-                else {
-                    const int l = 32 - __clz((int)waiting);
-                    const uint32_t upto = l >= 32 ? 0xffffffffu : ((1u << l) - 1u);
-                    r = r || (nearHit & below & ~upto) != 0;
-                    depth = l;
-                    const uint32_t bit = 1u << (l - 1);
-                    const uint32_t sib = ((uint32_t)stack[(uint32_t)l * stride] << 1) | (((sides >> (l - 1)) & 1u) ^ 1u);
-                    if (r) {
-                        nearHit |= bit;
-                        float tmf;
-                        const NodeRec ns = node_at_g(M, sib);
-                        const uint32_t ds = ns.data;
-                        int fs = rf.slow ? -1 : box_fast(ns.b, o, rf, ht, tmf);
-                        if (fs < 0) fs = box_hit_rcp(ns.b, o, d, ray_rcp(d), ht, tmf) ? 1 : 0;
-                        if (fs) { inFar |= bit; cur = sib; data = ds; st = (ds & 0x80000000u) ? 1 : 0; }
-                        else depth--; // stays in climb
-                    } else {
-                        inFar |= bit;
-                        cur = sib;
-                        data = M.bvh[sib].data;
-                        st = (data & 0x80000000u) ? 1 : 0;
-                    }
+        if (W.st == 1) {
+            const uint32_t count = ((W.data >> 28) & 7u) + 1, off = W.data & 0x0fffffffu;
+            W.r = leaf_hits(M.ltris, off, count, o, d, W.dlen, side, ht, hprim, hfront);
+            W.any |= W.r;
+            W.st = 2;
+        }
+#if BHRT_FUSED_CLIMB
+    }
+    {
+#else
+    } else {
+#endif
+        if (W.st == 2) {
+            const int depth = W.depth;
+            const uint32_t below = depth >= 32 ? 0xffffffffu : (depth > 0 ? ((1u << depth) - 1u) : 0u);
+            const uint32_t waiting = ~W.inFar & below;
+            if (!waiting) { W.depth = 0; W.st = 3; }
+            else {
+                const int l = 32 - __clz((int)waiting);
+                const uint32_t upto = l >= 32 ? 0xffffffffu : ((1u << l) - 1u);
+                W.r = W.r || (W.nearHit & below & ~upto) != 0;
+                W.depth = l;
+                const uint32_t bit = 1u << (l - 1);
+                const uint32_t sib = ((uint32_t)stack[(uint32_t)l * stride] << 1) | (((W.sides >> (l - 1)) & 1u) ^ 1u);
+                if (W.r) {
+                    W.nearHit |= bit;
+                    float tmf;
+                    const NodeRec ns = node_at_g(M, sib);
+                    const uint32_t ds = ns.data;
+                    int fs = W.rf.slow ? -1 : box_fast(ns.b, o, W.rf, ht, tmf);
+                    if (fs < 0) fs = box_hit_rcp(ns.b, o, d, ray_rcp(d), ht, tmf) ? 1 : 0;
+                    if (fs) { W.inFar |= bit; W.data = ds; W.st = (ds & 0x80000000u) ? 1 : 0; }
+                    else W.depth--; // stays in climb
+                } else {
+                    W.inFar |= bit;
+                    W.data = M.bvh[sib].data;
+                    W.st = (W.data & 0x80000000u) ? 1 : 0;
                 }
             }
         }
     }
-#ifdef BHRT_DEBUG_LONG_RAYS
-    if (dbg_mine > 20000u) printf("long ray: %u rounds (%u descend steps, %u leaves) o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) side %d hit t=%.9g prim %d\n", dbg_mine, dbg_desc, dbg_leaf, o.x, o.y, o.z, d.x, d.y, d.z, side, ht, hprim);
-#endif
-    return any;
+}
+template <class PathT>
+__device__ inline bool mesh_closest_vote(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront, PathT *stack, uint32_t stride)
+{
+    MeshWalk W;
+    walk_begin(M, W, o, d, ht);
+    while (true) {
+        const int nD = __popcll(__ballot(W.st == 0)), nL = __popcll(__ballot(W.st == 1)), nC = __popcll(__ballot(W.st == 2));
+        if (nD + nL + nC == 0) break;
+        walk_round(M, W, side, ht, hprim, hfront, stack, stride, nD, nL, nC);
+    }
+    return W.any;
 }
 
 // TriObj::ShadowRecursive + TraceBVHShadow (TriObj.cpp:41-66,272-307): pre-order walk (child1 then child2 — the
@@ -656,11 +728,8 @@ __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
             if (data & 0x80000000u) {
                 const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
                 float ht = BHRT_BIGFLOAT; // fresh HitInfo per leaf (TriObj.cpp:280)
-                for (uint32_t i = 0; i < count; i++) {
-                    float t;
-                    int fr;
-                    if (tri_hit(M.ltris[off + i], o, d, dlen, BHRT_HIT_FRONT, ht, t, fr)) { ht = t; found = true; t_min = t; }
-                }
+                int hp, hf;
+                if (leaf_hits(M.ltris, off, count, o, d, dlen, BHRT_HIT_FRONT, ht, hp, hf)) { found = true; t_min = ht; } // ht = the last accepted t
                 if (found) break;
                 desc = false;
             } else {
@@ -728,11 +797,8 @@ __device__ inline bool mesh_shadow_stack(const MeshRef &M, V3 o, V3 d, float t_m
             if (st == 1) {
                 const uint32_t count = ((data >> 28) & 7u) + 1, off = data & 0x0fffffffu;
                 float ht = BHRT_BIGFLOAT; // fresh HitInfo per leaf (TriObj.cpp:280)
-                for (uint32_t i = 0; i < count; i++) {
-                    float t;
-                    int fr;
-                    if (tri_hit(M.ltris[off + i], o, d, dlen, BHRT_HIT_FRONT, ht, t, fr)) { ht = t; found = true; t_min = t; }
-                }
+                int hp, hf;
+                if (leaf_hits(M.ltris, off, count, o, d, dlen, BHRT_HIT_FRONT, ht, hp, hf)) { found = true; t_min = ht; } // ht = the last accepted t
                 st = found ? 3 : 2;
             }
         } else {

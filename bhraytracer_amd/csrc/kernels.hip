@@ -406,6 +406,130 @@ __global__ void __launch_bounds__(kCamera ? kBlock : kMeshBlock, 6) k_trace_mesh
     // key-sorted rays are filed for shading by k_file_parked, in queue order instead of traversal order
     if (kCamera) file_ray(active ? shading_class(meta, hit) : (uint32_t)RC_NONE, i, slice & (BHRT_ORDER_SHARDS - 1), ord, cnt);
 }
+// The key-sorted parked rays of a later wave step, STREAMED through resident waves.  In k_trace_mesh a wave holds 64 rays until the
+// longest of them is through: over the wave's life 47 % of its lanes still have a ray (closed room, measured).  Here a wave takes the
+// next entries of the sorted list (one atomic on a cursor) whenever kStreamRefill of its lanes are free, so its lanes stay filled until
+// the list runs out.  A lane's ray goes through the same operation sequence as in trace_closest(start): the mesh walk it was parked at
+// (device_trace.h::walk_begin / walk_round, the rounds of mesh_closest_vote), then the remaining scene nodes in index order; a wave walks
+// ONE mesh at a time (M stays in scalar registers), lanes that reach another mesh node wait until the current walks are through.
+#ifndef BHRT_STREAM_REFILL
+#define BHRT_STREAM_REFILL 16
+#endif
+constexpr int kStreamRefill = BHRT_STREAM_REFILL;
+#ifndef BHRT_STREAM_OCC
+#define BHRT_STREAM_OCC 6 /* waves per SIMD the streaming kernels are compiled for */
+#endif
+#ifdef BHRT_DEBUG_STREAM
+__device__ unsigned long long g_stream_dbg[8]; // rounds, lanes with a walk, lanes in the round's phase, clocks in rounds, clocks outside, refills, descend / leaf rounds
+#endif
+template <int kPath> // 1: 16-bit path entries, 2: 32-bit (see k_trace_mesh)
+__global__ void __launch_bounds__(64, BHRT_STREAM_OCC) k_trace_mesh_stream(DevScene S, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
+{
+    typedef typename std::conditional<kPath == 2, uint32_t, uint16_t>::type PathT;
+    __shared__ PathT path[33 * 64];
+    const uint32_t total = ord.mesh_count[BHRT_ORDER_SHARDS];
+    const uint32_t lane = threadIdx.x;
+    PathT *stack = path + lane;
+    bool have = false, pending = false, exhausted = false;
+    uint32_t i = 0;
+    int n = 0, side = 0;
+    Hit hit = {BHRT_BIGFLOAT, -1, -1, 1};
+    MeshWalk W = {};
+    W.st = 3;
+    int cur_n = -1; // wave-uniform: the scene node whose mesh the wave walks
+    MeshRef M = mesh_ref(S, 0);
+#ifdef BHRT_DEBUG_STREAM
+    unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long c_mark = __builtin_readcyclecounter();
+#endif
+    for (;;) {
+        // (1) lanes through with their mesh: the rest of the scene graph (trace_closest's node loop from n + 1)
+        if (have && !pending && W.st == 3) {
+            const V3 o = v3(q.ox[i], q.oy[i], q.oz[i]), d = v3(q.dx[i], q.dy[i], q.dz[i]);
+            if (W.any) hit.node = n;
+            W.any = false;
+            for (n++; n < S.n_nodes; n++) {
+                const int type = S.nodes[n].obj_type;
+                if (type == BHRT_OBJ_NONE) continue;
+                if (type == BHRT_OBJ_MESH) { pending = true; break; }
+                V3 lp = o, ld = d;
+                local_ray(S, n, lp, ld);
+                float t;
+                int fr;
+                if (type == BHRT_OBJ_SPHERE) {
+                    if (sphere_hit(lp, ld, side, hit.t, t, fr)) { hit.t = t; hit.node = n; hit.prim = -1; hit.front = fr; }
+                } else if (type == BHRT_OBJ_PLANE) {
+                    if (plane_hit(lp, ld, side, hit.t, t, fr)) { hit.t = t; hit.node = n; hit.prim = -1; hit.front = fr; }
+                }
+            }
+            if (!pending) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; have = false; }
+        }
+        // (2) free lanes take the next rays of the list
+        if (!exhausted) {
+            const uint64_t idle = __ballot(!have);
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            if (n_idle >= (uint32_t)kStreamRefill) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&cnt->mesh_cursor.v, n_idle);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                exhausted = base + n_idle >= total;
+#ifdef BHRT_DEBUG_STREAM
+                dbg[5]++;
+#endif
+                const uint32_t k = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (!have && k < total) {
+                    i = ord.park_sorted[k];
+                    hit.t = h.t[i]; hit.node = h.node[i]; hit.prim = h.prim[i];
+                    const int fw = h.front[i];
+                    hit.front = fw & 0xff;
+                    n = (fw >> 8) - 1; // the mesh node the ray was parked at
+                    side = (int)(((q.meta ? q.meta[i] : 0u) >> 4) & 3u);
+                    have = true;
+                    pending = true;
+                }
+            }
+        }
+        if (!__ballot(have)) break; // the list has run out (a wave whose lanes are all free has just asked for more)
+        // (3) lanes waiting at a mesh node enter its BVH
+        const uint64_t waiting = __ballot(pending);
+        if (!__ballot(W.st != 3) && waiting) {
+            const int nn = __builtin_amdgcn_readlane(n, __ffsll((unsigned long long)waiting) - 1);
+            if (nn != cur_n) { cur_n = nn; M = mesh_ref(S, S.nodes[cur_n].mesh); }
+        }
+        if (pending && n == cur_n) {
+            V3 lp = v3(q.ox[i], q.oy[i], q.oz[i]), ld = v3(q.dx[i], q.dy[i], q.dz[i]);
+            local_ray(S, n, lp, ld);
+            walk_begin(M, W, lp, ld, hit.t);
+            pending = false;
+        }
+        // (4) rounds of the walk, until enough lanes are free again
+        const int n_wait = __popcll(__ballot(pending));
+#ifdef BHRT_DEBUG_STREAM
+        { const unsigned long long c = __builtin_readcyclecounter(); dbg[4] += c - c_mark; c_mark = c; }
+#endif
+        for (;;) {
+            const int nD = __popcll(__ballot(W.st == 0)), nL = __popcll(__ballot(W.st == 1)), nC = __popcll(__ballot(W.st == 2));
+            const int walking = nD + nL + nC;
+            if (walking == 0 || (!exhausted && 64 - walking - n_wait >= kStreamRefill)) break;
+#ifdef BHRT_DEBUG_STREAM
+#if BHRT_FUSED_CLIMB
+            dbg[0]++; dbg[1] += walking; dbg[2] += (nD >= nL && nD > 0) ? nD : nL;
+            if (nD >= nL && nD > 0) dbg[6]++; else if (nL > 0) dbg[7]++;
+#else
+            dbg[0]++; dbg[1] += walking; dbg[2] += (nD >= nL && nD >= nC) ? nD : (nL >= nC ? nL : nC);
+            if (nD >= nL && nD >= nC) dbg[6]++; else if (nL >= nC) dbg[7]++;
+#endif
+#endif
+            walk_round(M, W, side, hit.t, hit.prim, hit.front, stack, 64u, nD, nL, nC);
+        }
+#ifdef BHRT_DEBUG_STREAM
+        { const unsigned long long c = __builtin_readcyclecounter(); dbg[3] += c - c_mark; c_mark = c; }
+#endif
+    }
+#ifdef BHRT_DEBUG_STREAM
+    if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_stream_dbg[k], dbg[k]);
+#endif
+}
 // Files the finished mesh rays of a later wave step under their shading class, walking the parked list as it was filed
 // (queue order): k_shade then reads rays, hits and parent frames of neighbouring queue slots together (filed in the
 // key-sorted traversal order its loads scatter: C3 k_shade 15.5 vs 13.5 ms).
@@ -515,7 +639,7 @@ __global__ void __launch_bounds__(64) k_mesh_prefix(Counters *cnt, RayOrder ord)
     uint32_t tot = c;
     for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(tot, off); if ((int)s >= off) tot += t; }
     if (s < BHRT_ORDER_SHARDS) { ord.mesh_start[s] = incl - blocks; ord.mesh_count[s] = c; }
-    if (s == BHRT_ORDER_SHARDS - 1) { ord.mesh_start[BHRT_ORDER_SHARDS] = incl; ord.mesh_count[BHRT_ORDER_SHARDS] = tot; }
+    if (s == BHRT_ORDER_SHARDS - 1) { ord.mesh_start[BHRT_ORDER_SHARDS] = incl; ord.mesh_count[BHRT_ORDER_SHARDS] = tot; cnt->mesh_cursor.v = 0; }
 }
 
 // segment table of the shading order for k_shade (one tiny workgroup per wave step)
@@ -1807,6 +1931,8 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             if (hm[k].bvh_depth > 32) path_mode = 0;
         }
     }
+    // resident waves of the streaming mesh kernels (k_trace_mesh_stream): 6 per SIMD; BHRT_STREAM_WAVES=0 selects the launch-per-64-rays kernels
+    static const uint32_t stream_waves = getenv("BHRT_STREAM_WAVES") ? (uint32_t)atoi(getenv("BHRT_STREAM_WAVES")) : 256u * 4u * (uint32_t)BHRT_STREAM_OCC;
     RenderParams R;
     R.internal_bounces = o.internal_bounces; R.gi_bounces = o.gi_bounces; R.photon = o.photon_map;
     auto wall0 = std::chrono::steady_clock::now();
@@ -1906,6 +2032,10 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                     }
                     auto mesh_kernel = first_step ? (path_mode == 1 ? k_trace_mesh<true, 1> : path_mode == 2 ? k_trace_mesh<true, 2> : k_trace_mesh<true, 0>)
                                                   : (path_mode == 1 ? k_trace_mesh<false, 1> : path_mode == 2 ? k_trace_mesh<false, 2> : k_trace_mesh<false, 0>);
+                    if (!first_step && path_mode != 0 && stream_waves > 0)
+                        hipLaunchKernelGGL(path_mode == 1 ? k_trace_mesh_stream<1> : k_trace_mesh_stream<2>, dim3(std::min<uint32_t>((n_cur + 63) / 64, stream_waves)), dim3(64), 0, D->stream, D->S,
+                                           Q[cur], HB, RO, D->d_cnt);
+                    else
                     hipLaunchKernelGGL(mesh_kernel, first_step ? dim3(tg.x + BHRT_ORDER_SHARDS) /* shard segments padded to whole slices */ : dim3((n_cur + kMeshBlock - 1) / kMeshBlock),
                                        first_step ? tb : dim3(kMeshBlock), 0, D->stream, D->S, P, Q[cur], HB, RO, D->d_cnt);
                     if (!first_step) hipLaunchKernelGGL(k_file_parked, dim3(tg.x + BHRT_ORDER_SHARDS), tb, 0, D->stream, Q[cur], HB, RO, D->d_cnt);
@@ -1970,6 +2100,15 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             D->pass_hint_key = hint_key; D->pass_hint = pass_limit;
             continue;
         }
+#ifdef BHRT_DEBUG_STREAM
+        {
+            unsigned long long d[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            HIP_CHECK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_stream_dbg), sizeof(d)));
+            HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stream_dbg), z, sizeof(z)));
+            fprintf(stderr, "stream: %llu rounds (%llu descend, %llu leaf), walking %.3f, in phase %.3f, clocks in rounds %.3g outside %.3g, %llu refills\n", d[0], d[6], d[7],
+                    d[0] ? (double)d[1] / (64.0 * d[0]) : 0.0, d[0] ? (double)d[2] / (64.0 * d[0]) : 0.0, (double)d[3], (double)d[4], d[5]);
+        }
+#endif
         st->camera_samples += pass_camera; st->shadow_rays += pass_shadow; st->wave_iterations += pass_steps; st->deferred_rays += pass_deferred;
         if (o.photon_map && frame_marks.back() > 0) {
             // caustic term (MtlBlinn.cpp:329-342) of every frame of the pass in ONE gather: a gather launch lasts as long as its

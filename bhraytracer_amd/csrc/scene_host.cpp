@@ -475,7 +475,9 @@ struct BlobWriter {
     explicit BlobWriter(std::vector<uint8_t> &v) : b(v) {}
     uint64_t Append(const void *p, size_t n)
     {
-        while (b.size() % 16) b.push_back(0);
+        // every array starts a 128-byte line: a BVH node pair (64 B) is then one half line and never straddles two (16-byte starts
+        // put the pairs of the mesh scenes at 112 mod 128: two sectors per pair, two lines for every other pair)
+        b.resize((b.size() + 127) / 128 * 128, 0);
         uint64_t off = b.size();
         if (n) b.insert(b.end(), (const uint8_t *)p, (const uint8_t *)p + n);
         return off;

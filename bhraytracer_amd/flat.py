@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 MAGIC = 0x54524842
-VERSION = 8
+VERSION = 9
 BIGFLOAT = np.float32(1.0e30)
 
 OBJ_NONE, OBJ_SPHERE, OBJ_PLANE, OBJ_MESH = 0, 1, 2, 3

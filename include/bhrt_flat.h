@@ -20,7 +20,7 @@
 #include <stdint.h>
 
 #define BHRT_FLAT_MAGIC 0x54524842u /* "BHRT" */
-#define BHRT_FLAT_VERSION 8u
+#define BHRT_FLAT_VERSION 9u
 #define BHRT_MAX_NODE_DEPTH 8 /* scene-graph depth below the root the kernels support */
 #define BHRT_BIGFLOAT 1.0e30f  /* Scenes/scene.h:38 */
 
@@ -65,11 +65,13 @@ typedef struct bhrt_bvh_node {
  * the triangle alone): axis 0 = (y, z), 1 = (x, z), 2 = (x, y), 3 = none of the three comparisons holds (NaN normal: the
  * reference then works on zeros).  48 B */
 typedef struct bhrt_tri {
-    float p0[2], p1[2], p2[2];
+    /* first 20 bytes: what the plane part of the test reads (every triangle of a visited leaf); the rest only for a ray
+     * whose plane hit lies in range */
     float vN[3];
-    float vN_len;
     float vN_dot_v0;
+    float vN_len;
     uint32_t face_axis; /* triangle id (index into f[]) | axis << 30 */
+    float p0[2], p1[2], p2[2];
 } bhrt_tri;
 
 typedef struct bhrt_mesh {
