@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(kCamera ? kBlock : kMeshBlock, 6) k_trace_mesh
 // (device_trace.h::walk_begin / walk_round, the rounds of mesh_closest_vote), then the remaining scene nodes in index order; a wave walks
 // ONE mesh at a time (M stays in scalar registers), lanes that reach another mesh node wait until the current walks are through.
 #ifndef BHRT_STREAM_REFILL
-#define BHRT_STREAM_REFILL 16
+#define BHRT_STREAM_REFILL 32 /* lanes that have to be free before the wave takes new rays (16: +1-3 %; 24-48: the same) */
 #endif
 constexpr int kStreamRefill = BHRT_STREAM_REFILL;
 #ifndef BHRT_STREAM_OCC
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(64, BHRT_STREAM_OCC) k_trace_mesh_stream(DevSc
         // (4) rounds of the walk, until enough lanes are free again
         const int n_wait = __popcll(__ballot(pending));
 #ifdef BHRT_DEBUG_STREAM
-        { const unsigned long long c = __builtin_readcyclecounter(); dbg[4] += c - c_mark; c_mark = c; }
+        c_mark = __builtin_readcyclecounter();
 #endif
         for (;;) {
             const int nD = __popcll(__ballot(W.st == 0)), nL = __popcll(__ballot(W.st == 1)), nC = __popcll(__ballot(W.st == 2));
@@ -520,7 +520,13 @@ __global__ void __launch_bounds__(64, BHRT_STREAM_OCC) k_trace_mesh_stream(DevSc
             if (nD >= nL && nD >= nC) dbg[6]++; else if (nL >= nC) dbg[7]++;
 #endif
 #endif
+#ifdef BHRT_DEBUG_STREAM
+            const unsigned long long r0 = __builtin_readcyclecounter();
+#endif
             walk_round(M, W, side, hit.t, hit.prim, hit.front, stack, 64u, nD, nL, nC);
+#ifdef BHRT_DEBUG_STREAM
+            if (nD >= nL && nD > 0) dbg[4] += __builtin_readcyclecounter() - r0; // descend rounds
+#endif
         }
 #ifdef BHRT_DEBUG_STREAM
         { const unsigned long long c = __builtin_readcyclecounter(); dbg[3] += c - c_mark; c_mark = c; }
@@ -1826,6 +1832,9 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
     HIP_CHECK(hipMemsetAsync(D->d_n_heavy, 0, 4 * sizeof(uint32_t), D->stream));
     int lane_budget = BHRT_GATHER_LANE_BUDGET;
     if (const char *e = getenv("BHRT_GATHER_LANE_BUDGET")) lane_budget = std::max(1, atoi(e)); // test knob: a tiny budget sends every query through pass 2
+    // (Streaming the queries through resident waves, lanes refilled from a cursor as in k_trace_mesh_stream, is SLOWER here — 0.69 -> 0.81-1.01 s per
+    // frame for refill thresholds of 60-16 lanes: the 64 queries of a wave come from one cell and walk the tree in step, so their loads hit
+    // the same lines; refilled lanes are out of step with their neighbours and every load becomes a gather.  33 of 64 lanes busy is the cheaper evil.)
     if (n_walk > 0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_fast<Sink>), grid, block, 0, D->stream, sink, q0, n_walk, order, D->pm, radius, lane_budget, D->d_heavy,
                            D->d_long, D->d_n_heavy);
@@ -2063,6 +2072,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 if (H->n_meshes > 0) {
                     hipLaunchKernelGGL(k_trace_shadow_park, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis, RO, D->d_cnt);
                     hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
+                    // (streamed like k_trace_mesh_stream the any-hit walks gain nothing: they are short, C4 +4 ms, closed room -2 ms)
                     hipLaunchKernelGGL(path_mode == 1 ? k_shadow_mesh<1> : path_mode == 2 ? k_shadow_mesh<2> : k_shadow_mesh<0>, dim3(hg.x + BHRT_ORDER_SHARDS), hb, 0, D->stream, D->S, SQ, F.vis, RO);
                 } else hipLaunchKernelGGL(k_trace_shadow<false>, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis);
                 t.Stop();
@@ -2105,8 +2115,8 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             unsigned long long d[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIP_CHECK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_stream_dbg), sizeof(d)));
             HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stream_dbg), z, sizeof(z)));
-            fprintf(stderr, "stream: %llu rounds (%llu descend, %llu leaf), walking %.3f, in phase %.3f, clocks in rounds %.3g outside %.3g, %llu refills\n", d[0], d[6], d[7],
-                    d[0] ? (double)d[1] / (64.0 * d[0]) : 0.0, d[0] ? (double)d[2] / (64.0 * d[0]) : 0.0, (double)d[3], (double)d[4], d[5]);
+            fprintf(stderr, "stream: %llu rounds (%llu descend, %llu leaf), walking %.3f, in phase %.3f, clocks in rounds %.3g of which descend rounds %.3g, %llu refills\n", d[0], d[6],
+                    d[7], d[0] ? (double)d[1] / (64.0 * d[0]) : 0.0, d[0] ? (double)d[2] / (64.0 * d[0]) : 0.0, (double)d[3], (double)d[4], d[5]);
         }
 #endif
         st->camera_samples += pass_camera; st->shadow_rays += pass_shadow; st->wave_iterations += pass_steps; st->deferred_rays += pass_deferred;
