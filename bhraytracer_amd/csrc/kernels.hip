@@ -2115,6 +2115,12 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             unsigned long long d[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             HIP_CHECK(hipMemcpyFromSymbol(d, HIP_SYMBOL(g_stream_dbg), sizeof(d)));
             HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stream_dbg), z, sizeof(z)));
+            unsigned long long w[16], wz[16] = {};
+            HIP_CHECK(hipMemcpyFromSymbol(w, HIP_SYMBOL(g_walk_dbg), sizeof(w)));
+            HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_walk_dbg), wz, sizeof(wz)));
+            fprintf(stderr, "walk: descend bodies %llu (%.1f lanes), exact boxes %llu (%.1f lanes), climbs %llu (%.1f lanes), climbs after a hit %llu (%.1f lanes), triangle slots %llu (%.1f lanes), barycentric parts %llu (%.1f lanes), exact grazing quotients %llu; exact boxes by cause: slow %llu, hit test %llu, order %llu\n",
+                    w[0], w[0] ? (double)w[1] / w[0] : 0., w[2], w[2] ? (double)w[3] / w[2] : 0., w[4], w[4] ? (double)w[5] / w[4] : 0., w[6], w[6] ? (double)w[7] / w[6] : 0., w[8],
+                    w[8] ? (double)w[9] / w[8] : 0., w[10], w[10] ? (double)w[11] / w[10] : 0., w[12], w[13], w[14], w[15]);
             fprintf(stderr, "stream: %llu rounds (%llu descend, %llu leaf), walking %.3f, in phase %.3f, clocks in rounds %.3g of which descend rounds %.3g, %llu refills\n", d[0], d[6],
                     d[7], d[0] ? (double)d[1] / (64.0 * d[0]) : 0.0, d[0] ? (double)d[2] / (64.0 * d[0]) : 0.0, (double)d[3], (double)d[4], d[5]);
         }

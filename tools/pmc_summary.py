@@ -82,6 +82,8 @@ def main():
                 ent.update({c: s[c] for c in s})
                 if s.get("SQ_WAVES"):
                     ent["valu_insts_per_wave"] = s["SQ_INSTS_VALU"] / s["SQ_WAVES"]
+                if s.get("SQ_THREAD_CYCLES_VALU") and s.get("SQ_INSTS_VALU"):
+                    ent["valu_lanes_per_inst"] = s["SQ_THREAD_CYCLES_VALU"] / s["SQ_INSTS_VALU"]  # of 64: lanes enabled in an average VALU instruction
                 if s.get("SQ_WAVE_CYCLES"):
                     # quad-cycle units (MI355X_MICROARCH.md): share of the waves' resident time in which a VALU instruction issues
                     ent["valu_active_share_of_wave_time"] = s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"]
@@ -89,7 +91,7 @@ def main():
             per_launch[k + "_bytes_per_launch"] = (rd + wr) / n
         # the closest-hit trace of a wave step is k_trace_closest + (scenes with meshes) the parked-ray finish and its sort;
         # bench.py times them as one unit, so their traffic is summed per trace launch as well
-        group = [k for k in out if k in ("k_trace_closest", "k_trace_mesh", "k_park_count", "k_park_scatter", "k_scan_tiles", "k_scan_sums", "k_scan_add")]
+        group = [k for k in out if k in ("k_trace_closest", "k_trace_mesh", "k_trace_mesh_stream", "k_park_count", "k_park_scatter", "k_scan_tiles", "k_scan_sums", "k_scan_add")]
         if "k_trace_closest" in out:
             n = out["k_trace_closest"]["launches"]
             per_launch["k_trace_closest_bytes_per_launch"] = sum(out[k]["read_bytes"] + out[k]["written_bytes"] for k in group) / n
@@ -116,13 +118,13 @@ def main():
         if os.path.exists(sp):
             for r in csv.DictReader(open(sp)):
                 ktime[short(r["Name"])] += float(r["TotalDurationNs"]) * 1e-9
-        for k in ("k_shade", "k_trace_mesh", "k_shadow_mesh", "k_photon_gather_fast", "k_photon_gather_select"):
+        for k in ("k_shade", "k_trace_mesh_stream", "k_trace_mesh", "k_shadow_mesh", "k_photon_gather_fast", "k_photon_gather_select"):
             e = out.get(k)
             if e and frames and ktime.get(k) and e.get("SQ_INSTS_VALU"):
                 sec = ktime[k] / frames
                 e["seconds_per_frame"] = sec
                 e["valu_issue_frac"] = e["SQ_INSTS_VALU"] * 4.0 / (1024 * sec * 2.4e9)
-                name = {"k_trace_mesh": "k_trace_closest", "k_shadow_mesh": "k_trace_shadow", "k_photon_gather_fast": "k_photon_gather"}.get(k, k)
+                name = {"k_trace_mesh_stream": "k_trace_closest", "k_trace_mesh": "k_trace_closest", "k_shadow_mesh": "k_trace_shadow", "k_photon_gather_fast": "k_photon_gather"}.get(k, k)
                 per_launch.setdefault(name + "_valu_issue_frac", e["valu_issue_frac"])
         json.dump(out, open(os.path.join(dst, f"{wl}_pmc_one_frame.json"), "w"), indent=1)
         traffic[wl] = per_launch

@@ -12,5 +12,5 @@ rocprofv3 --kernel-trace --stats -d $OUT/trace_$WL -o $WL --output-format csv --
 grep "^{\"metric\"" $OUT/trace_$WL.log | tail -1 > $OUT/bench_under_rocprof_$WL.json
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$WL -o p --output-format csv -- python3 $R/tools/pmc_workload.py $WL > $OUT/pmc_fetch_$WL.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_$WL -o p --output-format csv -- python3 $R/tools/pmc_workload.py $WL > $OUT/pmc_write_$WL.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d $OUT/pmc_sq_$WL -o p --output-format csv -- python3 $R/tools/pmc_workload.py $WL > $OUT/pmc_sq_$WL.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY -d $OUT/pmc_sq_$WL -o p --output-format csv -- python3 $R/tools/pmc_workload.py $WL > $OUT/pmc_sq_$WL.log 2>&1
 echo done $TAG $WL
