@@ -96,6 +96,7 @@ struct Counters {
     // traced rays sorted for shading: class x shard element counts (see RayOrder)
     Line cls[4][BHRT_ORDER_SHARDS];
     Line n_slow;    // rays set aside in the slow queue (kernels.hip::SlowQueue), this pass
+    Line shade_done; // workgroups of the step's k_shade that have finished (the last one publishes the step's counters; it leaves 0 behind)
     Line mesh_cursor; // next entry of the parked list to hand out (k_trace_mesh_stream; zeroed by k_mesh_prefix)
 };
 #define BHRT_COUNTERS_HOST_BYTES (4 * 128)
