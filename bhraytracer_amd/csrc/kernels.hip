@@ -689,6 +689,13 @@ __global__ void __launch_bounds__(128) k_order_prefix(Counters *cnt, RayOrder or
     }
 }
 
+// k_shade's capacity flags: a RETURNING atomic whose result is consumed, so that the wave has the acknowledgement before it goes on — the flag
+// is then in place when the workgroup takes its ticket (the last ticket holder publishes the flags; a fire-and-forget atomic may still be in flight)
+__device__ inline void flag_overflow(Counters *cnt, uint32_t bit)
+{
+    const uint32_t old = atomicOr(&cnt->overflow.v, bit);
+    asm volatile("" ::"v"(old));
+}
 // The step's queue lengths for the host, written straight into pinned host memory (no copy engine packet, no event:
 // each of those costs the stream ~6 us of idle GPU per wave step).  The host spins on `seq` (WaitPublished).
 struct HostCounters { uint32_t n_next, n_shadow, n_frames, overflow, n_slow; uint32_t pad[11]; uint32_t seq; };
@@ -899,7 +906,7 @@ __device__ __forceinline__ void shade_block(const DevScene &S, const RenderParam
     // frame number = the segment's first frame (k_order_prefix) + the ray's place in the heavy list: no atomic, no barrier.
     // new_frame holds for every ray of a heavy segment and for no other (k_trace_closest files rays with this predicate).
     uint32_t f = ord.frame_base[seg] + local, u2;
-    if (new_frame && f >= R.cap_frames) { atomicOr(&cnt->overflow.v, 1u); new_frame = false; }
+    if (new_frame && f >= R.cap_frames) { flag_overflow(cnt, 1u); new_frame = false; }
 
     ShadeOut so;
     so.has_refr = so.has_gi = so.has_shadow = false;
@@ -1034,17 +1041,17 @@ __device__ __forceinline__ void shade_block(const DevScene &S, const RenderParam
     block_alloc3(lds, &cnt->n_next.v, so.has_refr ? 1u : 0u, so.has_gi ? 1u : 0u, &cnt->n_shadow.v, so.has_shadow ? 1u : 0u, nullptr, 0u, r0, r1, s0, u2);
     if (so.has_refr) {
         if (r0 < R.cap_rays) put_ray(qout, r0, so.ro, so.rd, ray_owner, so.rmeta, so.rctr);
-        else atomicOr(&cnt->overflow.v, 2u);
+        else flag_overflow(cnt, 2u);
     }
     if (so.has_gi) {
         if (r1 < R.cap_rays) put_ray(qout, r1, so.go, so.gd, ray_owner, make_meta(RK_GI, BHRT_HIT_FRONT, 0), 0);
-        else atomicOr(&cnt->overflow.v, 2u);
+        else flag_overflow(cnt, 2u);
     }
     if (so.has_shadow) {
         if (s0 < R.cap_shadow) {
             qs.ox[s0] = so.so.x; qs.oy[s0] = so.so.y; qs.oz[s0] = so.so.z; qs.dx[s0] = so.sd.x; qs.dy[s0] = so.sd.y; qs.dz[s0] = so.sd.z;
             qs.tmax[s0] = so.stmax; qs.frame[s0] = ray_owner;
-        } else atomicOr(&cnt->overflow.v, 4u);
+        } else flag_overflow(cnt, 4u);
     }
 }
 // The workgroup that finishes LAST hands the step's queue lengths to the host (what a one-lane kernel behind k_shade did: k_publish, ~6 us of
@@ -1056,9 +1063,9 @@ __global__ void __launch_bounds__(kShadeBlock, BHRT_SHADE_WAVES) k_shade(DevScen
 {
     shade_block<kCamera, kTex>(S, R, P, qin, hb, n, qout, qs, F, samples, cnt, ord);
     if (!pub) return;
-    __syncthreads(); // every wave's counter atomics are acknowledged (the barrier waits for the waves' outstanding memory operations)
-    // No agent-scope fence: only counters travel, all by atomics at agent scope — a release fence here writes the XCD's whole L2 back, per
-    // workgroup (measured: C2 frame 4.9 -> 9.8 ms).
+    __syncthreads(); // every wave is through: its queue counters were added to by returning atomics whose results it has used (block_alloc), its
+    // capacity flags likewise (flag_overflow) — all acknowledged.  No agent-scope fence: only counters travel, all by atomics at agent scope; a release
+    // fence here writes the XCD's whole L2 back, per workgroup (measured: C2 frame 4.9 -> 9.8 ms).
     if (threadIdx.x == 0 && atomicAdd(&cnt->shade_done.v, 1u) == gridDim.x - 1u) {
         __hip_atomic_store(&cnt->shade_done.v, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // for the next step's launch
         publish_counters(cnt, pub, seq);
