@@ -1980,6 +1980,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         int rc = EnsureWorkspace(D, pass_samples, frames_per_sample);
         if (rc) return rc;
         R.cap_rays = D->cap_rays; R.cap_shadow = D->cap_rays; R.cap_frames = D->cap_frames;
+        if (const char *e = getenv("BHRT_TEST_FRAME_CAP")) R.cap_frames = std::min<uint32_t>(R.cap_frames, (uint32_t)std::max(1, atoi(e))); // test knob: a pass that overflows
         if (o.photon_map) {
             if (D->ph_frames_cap < D->cap_frames) {
                 if (D->d_ph_frames) (void)hipFree(D->d_ph_frames);

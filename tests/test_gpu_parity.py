@@ -345,6 +345,25 @@ def test_no_jitter_no_gamma_options(gpu, load_scene, O):
     assert np.array_equal(rgb, q)
 
 
+def test_a_pass_that_overflows_its_frame_pool_is_cut_in_half_and_redone(gpu, load_scene, monkeypatch):
+    """RenderRange's retry: k_shade flags a Shade() frame beyond the pool (cap_frames), the flag reaches the host with the step's counters
+    (published by k_shade's last workgroup), the pass is redone with half the pixels — and the frame is the same, byte for byte, with
+    the statistics of the passes that completed only."""
+    sc = load_scene("c2_glass_small")
+    opts = gpu.default_opts(spp=4, gi_bounces=3, seed=9)
+    base_rgb, base_rad, st = sc.render(opts)
+    assert st.passes == 1
+    frames_needed = st.shade_calls if hasattr(st, "shade_calls") else st.camera_samples * 2
+    monkeypatch.setenv("BHRT_TEST_FRAME_CAP", str(max(1, int(frames_needed) // 3)))  # a third of what the one-pass frame needs
+    rgb, rad, st2 = sc.render(opts)
+    monkeypatch.delenv("BHRT_TEST_FRAME_CAP")
+    assert st2.passes >= 3
+    assert np.array_equal(rgb, base_rgb) and same_bits(rad, base_rad)
+    assert (st2.camera_samples, st2.closest_rays, st2.shadow_rays) == (st.camera_samples, st.closest_rays, st.shadow_rays)
+    rgb3, rad3, st3 = sc.render(opts)  # the knob is gone, the remembered pass size of the scene/options is not a smaller frame pool
+    assert np.array_equal(rgb3, base_rgb) and same_bits(rad3, base_rad)
+
+
 # ---------------------------------------------------------------------------------------------------- full-size properties
 def test_tile_partition_and_pass_size_invariance_full_size(gpu, load_scene):
     """BASELINE config 2 at full size (1920x1080): the image must not depend on how it is cut into passes or
