@@ -194,6 +194,50 @@ def test_mesh_with_more_than_2_17_bvh_nodes(gpu, B, O, tmp_path):
     assert B.Scene(str(xml), bvh_device=0).flat_bytes() == blob
 
 
+def test_rays_that_go_through_several_different_meshes(gpu, B, O, tmp_path):
+    """Three mesh nodes of two different meshes (one of them glass, one inside a rotated group) in a closed box: a GI or refraction ray
+    enters one mesh's box after the other, so in the streamed mesh kernel (k_trace_mesh_stream: a wave walks ONE mesh at a time) lanes
+    wait at a mesh node while their wave walks another mesh, and a ray's hit so far comes from an earlier mesh.  Every pixel's primary hit
+    and the per-sample radiance of the whole (small) frame against the oracle."""
+    import shutil, sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_mesh
+    gen_mesh.generate(str(tmp_path / "mesh_b.obj"), 20)  # 800 triangles; mesh_small.obj has 288
+    shutil.copy(os.path.join(SCENES, "mesh_small.obj"), tmp_path / "mesh_small.obj")
+    xml = tmp_path / "meshes.xml"
+    xml.write_text("""<xml><scene><background r="0.1" g="0.1" b="0.2"/><environment value="0.4"/>
+      <object type="plane" name="floor" material="wall"><scale value="14"/></object>
+      <object type="plane" name="back" material="wall"><scale value="14"/><rotate angle="90" x="1"/><translate y="9" z="6"/></object>
+      <object type="obj" name="mesh_small.obj" material="glass"><scale value="2.2"/><translate x="-3" y="1" z="2.4"/></object>
+      <object type="obj" name="mesh_b.obj" material="red"><scale x="2.5" y="2" z="2.8"/><rotate angle="35" z="1"/><translate x="2.5" y="3" z="2.9"/></object>
+      <object name="grp"><rotate angle="-20" z="1"/><translate x="0.5" y="-2.5" z="0"/>
+        <object type="obj" name="mesh_small.obj" material="red"><scale value="1.3"/><translate z="1.4"/></object>
+        <object type="sphere" name="s" material="mirror"><scale value="0.9"/><translate x="2.6" z="0.9"/></object>
+      </object>
+      <material type="blinn" name="wall"><diffuse r="0.7" g="0.7" b="0.65"/><specular value="0.1"/><glossiness value="20"/></material>
+      <material type="blinn" name="red"><diffuse r="0.8" g="0.25" b="0.2"/><specular value="0.5"/><glossiness value="60"/></material>
+      <material type="blinn" name="mirror"><diffuse value="0.05"/><specular value="0.9"/><glossiness value="2000"/></material>
+      <material type="blinn" name="glass"><diffuse value="0.05"/><specular value="0.8"/><glossiness value="80"/><refraction value="0.85" index="1.5"/><absorption r="0.05" g="0.02" b="0.1"/></material>
+      <light type="point" name="p"><intensity value="260"/><position x="-2" y="-9" z="14"/><size value="1.5"/></light>
+      <light type="ambient" name="a"><intensity value="0.1"/></light>
+      </scene><camera><position x="0.5" y="-17" z="6.5"/><target x="0" y="1" z="2.2"/><up z="1"/><fov value="38"/><width value="128"/><height value="96"/></camera></xml>""")
+    sc = B.Scene(str(xml))
+    assert sc.info.n_triangles == 288 + 800
+    blob = sc.flat_bytes()
+    fv = sc.flat_view()
+    assert sum(1 for n in fv.nodes if n.obj_type == 3) == 3 and len(fv.meshes) >= 2
+    o, d = O.primary_rays(fv)
+    for side in (1, 3):
+        h, r = sc.trace_closest(o, d, side), O.trace_closest(blob, o, d, side)
+        assert np.array_equal(h["node"], r["node"]) and np.array_equal(h["prim"], r["prim"]) and same_bits(h["t"], r["t"])
+    hit_mesh_nodes = {int(n) for n in np.unique(r["node"]) if n >= 0 and fv.nodes[int(n)].obj_type == 3}
+    assert len(hit_mesh_nodes) == 3  # all three mesh nodes are in view
+    gs, st = sc.render_samples(B.default_opts(spp=4, gi_bounces=3, seed=21), 0, 0, sc.width, sc.height)
+    ro = O.render(blob, sc.width, sc.height, 4, gi=3, seed=21, region=(0, 0, sc.width, sc.height))
+    assert same_bits(gs, ro["samples"])
+    assert st.closest_rays > 3 * st.camera_samples
+
+
 def test_nested_scene_graph_depth3(gpu, B, O, tmp_path):
     # recursive() back-transforms only through the hit node and its direct parent (Main.cpp:407-412, SURVEY.md Q6):
     # a depth-3 node leaves p/N in its grandparent's space; t and node index are what the tracer returns
