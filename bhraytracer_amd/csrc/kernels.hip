@@ -1348,23 +1348,46 @@ __device__ inline uint32_t gather_cell(const GatherGrid &G, V3 p)
 // Queries that cannot meet a photon — farther than the radius from the photons' bounds (most pixels of a caustic scene), or
 // frames without the term — are answered here and left out of the order: pass 1 then runs over the rest only.
 #define BHRT_GATHER_NO_CELL 0xffffffffu
+// One add per wave and cell instead of one per lane: the 64 queries of a wave are mostly the samples of ONE pixel (frames are numbered in the
+// order of the heavy list, which a camera wave fills with its 64 slots), i.e. one or two cells — and a lane's atomic costs a 32-byte sector
+// of L2 traffic whatever it adds (5.8e8 queries per C5 frame: the two sort kernels were bound by exactly that).  Up to kCellLeaders cells per wave
+// are handled by a leader each; lanes of further cells add for themselves.  Returns the lane's slot in its cell (the value its own atomicAdd
+// would have returned, up to the order among the lanes of one wave); all lanes of the wave must call it (active = has a cell).
+constexpr int kCellLeaders = 4;
+__device__ inline uint32_t cell_add_wave(uint32_t *cells, uint32_t c, bool active)
+{
+    const uint32_t lane = __lane_id();
+    uint64_t todo = __ballot(active);
+    uint32_t slot = 0;
+    for (int k = 0; k < kCellLeaders && todo; k++) {
+        const int lead = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)c, lead);
+        const uint64_t same = __ballot(active && c == cl) & todo;
+        uint32_t base = 0;
+        if ((int)lane == lead) base = atomicAdd(&cells[cl], (uint32_t)__popcll(same));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, lead);
+        if ((same >> lane) & 1ull) slot = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) slot = atomicAdd(&cells[c], 1u);
+    return slot;
+}
 template <class Sink>
 __global__ void __launch_bounds__(kBlock) k_gather_cell_count(Sink sink, uint32_t q0, uint32_t cnt, GatherGrid G, PhotonMapDev M, float radius, uint32_t *cell_of,
                                                               uint32_t *cell_count)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cnt) return;
-    const uint32_t q = q0 + i;
-    if (sink.skip(q)) { cell_of[i] = BHRT_GATHER_NO_CELL; return; }
-    const V3 p = sink.pos(q);
-    if (photon_outside_bounds(M, p, radius)) { // photon_estimate_fast's own first test: no photon, zero estimate
-        cell_of[i] = BHRT_GATHER_NO_CELL;
-        sink.done(q, false, v3(0, 0, 0), v3(0, 0, 0));
-        return;
+    uint32_t c = BHRT_GATHER_NO_CELL;
+    if (i < cnt) {
+        const uint32_t q = q0 + i;
+        if (!sink.skip(q)) {
+            const V3 p = sink.pos(q);
+            if (photon_outside_bounds(M, p, radius)) sink.done(q, false, v3(0, 0, 0), v3(0, 0, 0)); // photon_estimate_fast's own first test: no photon, zero estimate
+            else c = gather_cell(G, p);
+        }
+        cell_of[i] = c;
     }
-    const uint32_t c = gather_cell(G, p);
-    cell_of[i] = c;
-    atomicAdd(&cell_count[c], 1u);
+    cell_add_wave(cell_count, c, c != BHRT_GATHER_NO_CELL);
 }
 // exclusive scan of cell_count[BHRT_GATHER_CELLS] in place, three launches: per-block sums, scan of the sums, add back
 constexpr uint32_t kScanBlock = 1024, kScanPerThread = 8, kScanTile = kScanBlock * kScanPerThread;
@@ -1415,9 +1438,9 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t *data, uint32_
 __global__ void __launch_bounds__(kBlock) k_gather_cell_scatter(uint32_t q0, uint32_t cnt, const uint32_t *cell_of, uint32_t *cell_cursor, uint32_t *order)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cnt) return;
-    const uint32_t c = cell_of[i];
-    if (c != BHRT_GATHER_NO_CELL) order[atomicAdd(&cell_cursor[c], 1u)] = q0 + i;
+    const uint32_t c = i < cnt ? cell_of[i] : BHRT_GATHER_NO_CELL;
+    const uint32_t slot = cell_add_wave(cell_cursor, c, c != BHRT_GATHER_NO_CELL);
+    if (c != BHRT_GATHER_NO_CELL) order[slot] = q0 + i;
 }
 
 // Pass 1: every query walks the map without a candidate list (photon_estimate_fast).  Queries that meet their 1000th
