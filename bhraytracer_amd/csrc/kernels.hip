@@ -1591,6 +1591,7 @@ __global__ void __launch_bounds__(kBlock) k_tiles_unpack(const uint8_t *gathered
 // ================================================================================================
 struct DeviceState {
     int device = -1;
+    uint32_t n_cus = 256; // compute units of the device (hipDeviceProp_t::multiProcessorCount): sizes the grids of the resident-wave kernels
     uint8_t *d_blob = nullptr;
     int32_t *d_chain = nullptr;
     float *d_aux = nullptr; // mat_r0 + light_pick (DevScene)
@@ -1904,7 +1905,7 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
     uint32_t n_exact = 0;
     if (n_sel_heavy + n_long) {
         HIP_CHECK(hipMemsetAsync(D->d_n_heavy, 0, 8 * sizeof(uint32_t), D->stream));
-        const uint32_t sel_waves = 256u * BHRT_SEL_WAVES_PER_CU; // persistent one-wave workgroups, each with its scratch (candidates 24 KB + stack spill 48 KB)
+        const uint32_t sel_waves = D->n_cus * BHRT_SEL_WAVES_PER_CU; // persistent one-wave workgroups, each with its scratch (candidates 24 KB + stack spill 48 KB)
         if (!D->d_sel) HIP_CHECK(hipMalloc(&D->d_sel, (size_t)sel_waves * BHRT_SEL_SCRATCH_WORDS * sizeof(uint32_t)));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_select<Sink>), dim3(std::min<uint32_t>(n_sel_heavy + n_long, sel_waves)), dim3(64), 0, D->stream, sink, D->d_heavy,
                            n_sel_heavy, D->d_long, n_long, D->pm, radius, undecided, D->d_n_heavy, D->d_knn, D->d_sel, D->photon_exact);
@@ -1989,7 +1990,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         }
     }
     // resident waves of the streaming mesh kernels (k_trace_mesh_stream): 6 per SIMD; BHRT_STREAM_WAVES=0 selects the launch-per-64-rays kernels
-    static const uint32_t stream_waves = getenv("BHRT_STREAM_WAVES") ? (uint32_t)atoi(getenv("BHRT_STREAM_WAVES")) : 256u * 4u * (uint32_t)BHRT_STREAM_OCC;
+    const uint32_t stream_waves = getenv("BHRT_STREAM_WAVES") ? (uint32_t)atoi(getenv("BHRT_STREAM_WAVES")) : D->n_cus * 4u * (uint32_t)BHRT_STREAM_OCC;
     RenderParams R;
     R.internal_bounces = o.internal_bounces; R.gi_bounces = o.gi_bounces; R.photon = o.photon_map;
     auto wall0 = std::chrono::steady_clock::now();
@@ -2236,6 +2237,10 @@ try {
     DeviceState *D = new DeviceState;
     D->device = device;
     scene->dev = D;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) D->n_cus = (uint32_t)cus;
+    }
     const std::vector<uint8_t> &blob = scene->flat.blob;
     const bhrt_flat_header *H = scene->flat.hdr();
     HIP_CHECK(hipStreamCreate(&D->stream));
