@@ -8,7 +8,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import same_bits
+from conftest import SCENES, same_bits
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4  # north_star's per-channel radiance tolerance; the assertions below are stronger (identical bits)
@@ -166,3 +166,38 @@ def test_c3_room_partition_and_pass_invariance(gpu, load_scene):
         m = BD.owned_mask(1920, 1080, 32, r, 4).numpy()
         acc[m] = rad[m]
     assert same_bits(acc, base_rad)
+
+
+# ---------------------------------------------------------------------------------------------------- whole frames
+@pytest.mark.parametrize("name,spp", [("c2_glass", 2), ("c3_mesh", 2), ("c3_room", 2), ("c4_mesh_4k", 1)])
+def test_every_sample_of_a_whole_frame_vs_oracle(gpu, load_scene, O, name, spp):
+    """Not a region: EVERY sample of the full-size frame (2.07 M / 8.29 M pixels, GI depth 3, 16 internal bounces) against the oracle's
+    keyed-RNG run of the same frame — 0.6-3 s of oracle time on the box's 16 cores.  Identical bits."""
+    sc = load_scene(name)
+    gs, st = sc.render_samples(gpu.default_opts(spp=spp, gi_bounces=3, seed=77), 0, 0, sc.width, sc.height)
+    ro = O.render(sc.flat_bytes(), sc.width, sc.height, spp, gi=3, seed=77, region=(0, 0, sc.width, sc.height), threads=16)
+    assert gs.shape[0] == sc.width * sc.height and st.camera_samples == sc.width * sc.height * spp
+    assert same_bits(gs, ro["samples"])
+    assert same_bits(sc.render(gpu.default_opts(spp=spp, gi_bounces=3, seed=77))[1].reshape(-1, 3), ro["radiance"].reshape(-1, 3))
+
+
+def test_every_sample_of_a_whole_caustic_frame_vs_oracle(gpu, load_scene, O):
+    """BASELINE config 5's scene at 1920x1080 with a 200 k-photon caustic map (keyed emission: the same map on both sides), every sample of
+    the frame: the exact replay gives the oracle's bits, the one-wave-per-query selection stays within north_star's 1e-4 (measured 5e-6)."""
+    import os
+    sc = gpu.Scene(os.path.join(SCENES, "c5_caustics_hd.xml"))  # a scene of its own: the photon map stays with it
+    n_photons = 200000
+    sc.photon_build(gpu.default_opts(seed=3), n_photons)
+    bal, _, _ = O.photon_build(sc.flat_bytes(), n_photons, seed=3)
+    assert np.array_equal(sc.photon_get(), bal)
+    region = (0, 0, sc.width, sc.height)
+    opts = gpu.default_opts(spp=1, gi_bounces=2, seed=3, photon_map=1)
+    opts.photon_exact = 1
+    gx, stx = sc.render_samples(opts, *region)
+    ro = O.render(sc.flat_bytes(), sc.width, sc.height, 1, gi=2, seed=3, region=region, photon=1, threads=16)
+    assert same_bits(gx, ro["samples"])
+    assert stx.photon_heavy_queries > 5000 and stx.photon_exact_queries >= stx.photon_heavy_queries
+    opts.photon_exact = 0
+    gs, st = sc.render_samples(opts, *region)
+    assert np.nanmax(np.abs(gs - ro["samples"])) <= TOL
+    assert st.photon_heavy_queries == stx.photon_heavy_queries and st.photon_exact_queries <= st.photon_heavy_queries // 20
