@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Whole-frame parity soak (needs a GPU; the oracle is the checker): every sample of full-size frames of the bench scenes, several seeds,
+HIP path against the oracle's keyed-RNG run, bit for bit.  ~100 s on a GPU box for 3.3e8 samples / 1.9e9 rays.
+Usage: python tools/soak_parity.py"""
+import sys, os, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import bhraytracer_amd as B, oracle_lib as O
+total = 0; bad = 0; rays = 0
+t00 = time.time()
+for name, spp, seeds in (("c3_room", 16, (1, 2, 3, 4)), ("c3_mesh", 16, (1, 2)), ("c4_mesh_4k", 4, (1, 2)), ("c2_glass", 16, (1, 2))):
+    sc = B.Scene(os.path.join("tests/scenes", name + ".xml")); blob = sc.flat_bytes()
+    for seed in seeds:
+        t0 = time.time()
+        gs, st = sc.render_samples(B.default_opts(spp=spp, gi_bounces=3, seed=seed), 0, 0, sc.width, sc.height)
+        ro = O.render(blob, sc.width, sc.height, spp, gi=3, seed=seed, region=(0, 0, sc.width, sc.height), threads=16)["samples"]
+        same = (gs.view(np.uint32) == ro.view(np.uint32)) | (np.isnan(gs) & np.isnan(ro))
+        nb = int((~same).sum())
+        total += gs.shape[0] * spp; bad += nb; rays += st.closest_rays + st.shadow_rays
+        print(name, "spp", spp, "seed", seed, "%.0fs" % (time.time() - t0), "mismatching values:", nb, "deferred (axis-parallel) rays", st.deferred_rays, flush=True)
+        del gs, ro, same
+print("samples compared: %d, rays behind them: %d, mismatching values: %d, %.0f s" % (total, rays, bad, time.time() - t00))
