@@ -2319,6 +2319,7 @@ try {
         float r = sqrtf(x) * 0.5f;
         S.tapx[i] = r * dm::sinf_(y * (float)M_PI * 2);
         S.tapy[i] = r * dm::cosf_(y * (float)M_PI * 2);
+        if (!(fabsf(S.tapx[i]) <= 0.5f && fabsf(S.tapy[i]) <= 0.5f)) { SetError("footprint tap outside the half-unit disc"); return BHRT_ERR_UNSUPPORTED; } // device_shade.h::checker_taps_in_one_cell relies on it
     }
     return BHRT_OK;
 } catch (...) { return bhrt::AbiException(); }
