@@ -238,6 +238,31 @@ def test_rays_that_go_through_several_different_meshes(gpu, B, O, tmp_path):
     assert st.closest_rays > 3 * st.camera_samples
 
 
+@pytest.mark.parametrize("tex_xf", ['<scale x="0.1" y="0.1"/>', '<scale x="0.013" y="0.31"/><rotate angle="33" z="1"/><translate x="0.21" y="-0.37"/>',
+                                    '<scale x="3" y="2"/>'])
+def test_checker_footprints_from_inside_one_cell_to_the_horizon(gpu, B, O, tmp_path, tex_xf):
+    """Texture::Sample's 31 footprint taps on a checker (scene.h:318-337; device_shade.h::checker_taps_in_one_cell skips the lookups when the
+    footprint provably stays inside one half-tile): a large textured ground seen from low above it — footprints from a fraction of a cell
+    under the camera to hundreds of cells at the horizon, cell edges at every distance, also through a rotated, anisotropic texture transform
+    and with a texture coarser than the plane.  Every sample of the frame against the oracle, which looks all 32 taps up."""
+    xml = tmp_path / "checker.xml"
+    xml.write_text(f"""<xml><scene><background r="0.2" g="0.3" b="0.5"/><environment value="0.6"/>
+      <object type="plane" name="ground" material="g"><scale value="60"/></object>
+      <object type="plane" name="wall" material="w"><scale x="30" y="8" z="1"/><rotate angle="90" x="1"/><translate y="40" z="8"/></object>
+      <object type="sphere" name="s" material="m"><scale value="2"/><translate x="3" y="6" z="2"/></object>
+      <material type="blinn" name="g"><diffuse r="1" g="0.9" b="0.8" texture="checkerboard"><color1 r="0.1" g="0.15" b="0.2"/><color2 r="0.9" g="0.8" b="0.7"/>{tex_xf}</diffuse>
+        <specular r="0.6" g="0.6" b="0.6" texture="checkerboard"><color1 value="0.1"/><color2 value="0.9"/><scale x="0.07" y="0.05"/></specular><glossiness value="40"/></material>
+      <material type="blinn" name="w"><diffuse value="0.8" texture="checkerboard"><color1 r="0.7" g="0.2" b="0.2"/><color2 value="0.9"/><scale x="0.05" y="0.2"/></diffuse><specular value="0.2"/><glossiness value="10"/></material>
+      <material type="blinn" name="m"><diffuse value="0.1"/><specular value="0.9"/><glossiness value="500"/></material>
+      <light type="point" name="p"><intensity value="700"/><position x="-10" y="-5" z="25"/></light>
+      </scene><camera><position x="0" y="-30" z="1.2"/><target x="0" y="10" z="1"/><up z="1"/><fov value="55"/><width value="320"/><height value="200"/></camera></xml>""")
+    sc = B.Scene(str(xml))
+    gs, st = sc.render_samples(B.default_opts(spp=3, gi_bounces=2, seed=4), 0, 0, sc.width, sc.height)
+    ro = O.render(sc.flat_bytes(), sc.width, sc.height, 3, gi=2, seed=4, region=(0, 0, sc.width, sc.height), threads=16)
+    assert same_bits(gs, ro["samples"])
+    assert len(np.unique(gs[:, :, 0])) > 1000  # the checker is there, filtered: far more than two shades
+
+
 def test_nested_scene_graph_depth3(gpu, B, O, tmp_path):
     # recursive() back-transforms only through the hit node and its direct parent (Main.cpp:407-412, SURVEY.md Q6):
     # a depth-3 node leaves p/N in its grandparent's space; t and node index are what the tracer returns
