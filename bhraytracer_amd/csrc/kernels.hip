@@ -856,30 +856,41 @@ __device__ inline void shade_entry(const DevScene &S, const RenderParams &R, con
 #ifndef BHRT_SHADE_WAVES
 #define BHRT_SHADE_WAVES 4 /* waves per SIMD the register allocation must allow */
 #endif
-template <bool kCamera, bool kTex>
+// kFused (camera step of a scene without meshes): the kernel traces its camera rays itself, in slot order — no k_trace_closest in front of it (which
+// computes the same camera ray, ~300 instructions, and writes 24-byte hit records this kernel reads back), no shading order (all samples of a pixel
+// sit in one wave: hits and misses are as uniform per workgroup in slot order as in the sorted one), frame numbers from one atomic per workgroup.
+template <bool kCamera, bool kTex, bool kFused = false>
 __device__ __forceinline__ void shade_block(const DevScene &S, const RenderParams &R, const PassInfo &P, const RayQueue &qin, const HitBuf &hb, uint32_t n, const RayQueue &qout,
                                             const ShadowQueue &qs, const Frames &F, float *samples, Counters *cnt, const RayOrder &ord)
 {
+    static_assert(!kFused || kCamera, "only camera rays are traced in the shading kernel");
     __shared__ BlockAllocLds lds;
-    // this workgroup's slice of the shading order: segments (class, shard) in class-major order, each padded to whole
-    // workgroups; seg_start[] (k_order_prefix) is ascending, the segment is the last one starting at or before blockIdx
-    constexpr uint32_t kSegs = 3 * BHRT_ORDER_SHARDS;
-    __shared__ uint32_t s_seg;
-    if (threadIdx.x < 64) {
-        const uint32_t l = threadIdx.x;
-        const uint32_t a = ord.seg_start[l], b = (l + 64 < kSegs) ? ord.seg_start[l + 64] : 0xffffffffu;
-        const uint32_t n_le = (uint32_t)__popcll(__ballot(a <= blockIdx.x)) + (uint32_t)__popcll(__ballot(b <= blockIdx.x));
-        if (l == 0) s_seg = n_le - 1; // seg_start[0] == 0 <= blockIdx always
+    uint32_t seg = 0, local = 0, i;
+    bool active;
+    if (kFused) {
+        i = blockIdx.x * kShadeBlock + threadIdx.x;
+        active = i < n;
+        if (!active) i = 0;
+    } else {
+        // this workgroup's slice of the shading order: segments (class, shard) in class-major order, each padded to whole
+        // workgroups; seg_start[] (k_order_prefix) is ascending, the segment is the last one starting at or before blockIdx
+        constexpr uint32_t kSegs = 3 * BHRT_ORDER_SHARDS;
+        __shared__ uint32_t s_seg;
+        if (threadIdx.x < 64) {
+            const uint32_t l = threadIdx.x;
+            const uint32_t a = ord.seg_start[l], b = (l + 64 < kSegs) ? ord.seg_start[l + 64] : 0xffffffffu;
+            const uint32_t n_le = (uint32_t)__popcll(__ballot(a <= blockIdx.x)) + (uint32_t)__popcll(__ballot(b <= blockIdx.x));
+            if (l == 0) s_seg = n_le - 1; // seg_start[0] == 0 <= blockIdx always
+        }
+        __syncthreads();
+        seg = s_seg;
+        if (blockIdx.x >= ord.seg_start[kSegs]) return; // uniform per workgroup: beyond the last segment
+        const uint32_t seg_cnt = ord.seg_count[seg];
+        const uint32_t bb = blockIdx.x - ord.seg_start[seg];
+        local = bb * kShadeBlock + threadIdx.x;
+        active = local < seg_cnt;
+        i = active ? ord.idx[(size_t)seg * ord.shard_cap + local] : 0u;
     }
-    __syncthreads();
-    const uint32_t seg = s_seg;
-    if (blockIdx.x >= ord.seg_start[kSegs]) return; // uniform per workgroup: beyond the last segment
-    const uint32_t seg_cnt = ord.seg_count[seg];
-    const uint32_t bb = blockIdx.x - ord.seg_start[seg];
-    const uint32_t local = bb * kShadeBlock + threadIdx.x;
-    bool active = local < seg_cnt;
-    const uint32_t i = active ? ord.idx[(size_t)seg * ord.shard_cap + local] : 0u;
-    (void)n;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1);
     uint32_t owner = 0, meta = 0, ctr = 0;
     Hit hit = {BHRT_BIGFLOAT, -1, -1, 1};
@@ -887,10 +898,12 @@ __device__ __forceinline__ void shade_block(const DevScene &S, const RenderParam
         fetch_ray<kCamera>(S, P, qin, i, o, d, meta);
         active = (meta & 15u) != RK_DEAD;
     }
+    if (kFused) // recursive() (Main.cpp:389) for the camera ray, as k_trace_closest<false, true, false> runs it
+        trace_closest<false>(S, o, d, BHRT_HIT_FRONT, hit, active, nullptr, 0, false, nullptr, (uint16_t *)nullptr, 0, BHRT_LDS_NODES, true);
     if (active) {
         if (kCamera) { owner = i; ctr = 0; } // the sample slot
         else { owner = qin.frame[i]; ctr = (meta & 15u) != RK_GI ? qin.rng_ctr[i] : 0u; }
-        hit.t = hb.t[i]; hit.node = hb.node[i]; hit.prim = hb.prim[i]; hit.front = hb.front[i];
+        if (!kFused) { hit.t = hb.t[i]; hit.node = hb.node[i]; hit.prim = hb.prim[i]; hit.front = hb.front[i]; }
     }
     const uint32_t kind = meta & 15u;
     int bounce = (int)((meta >> 8) & 0xffu);
@@ -905,7 +918,9 @@ __device__ __forceinline__ void shade_block(const DevScene &S, const RenderParam
     }
     // frame number = the segment's first frame (k_order_prefix) + the ray's place in the heavy list: no atomic, no barrier.
     // new_frame holds for every ray of a heavy segment and for no other (k_trace_closest files rays with this predicate).
-    uint32_t f = ord.frame_base[seg] + local, u2;
+    uint32_t f, u2;
+    if (kFused) { uint32_t u0, u1; block_alloc3(lds, &cnt->n_frames.v, new_frame ? 1u : 0u, 0u, nullptr, 0u, nullptr, 0u, f, u0, u1, u2); } // frame numbers: one atomic per workgroup
+    else f = ord.frame_base[seg] + local;
     if (new_frame && f >= R.cap_frames) { flag_overflow(cnt, 1u); new_frame = false; }
 
     ShadeOut so;
@@ -1057,11 +1072,11 @@ __device__ __forceinline__ void shade_block(const DevScene &S, const RenderParam
 // The workgroup that finishes LAST hands the step's queue lengths to the host (what a one-lane kernel behind k_shade did: k_publish, ~6 us of
 // launch and ~5 us of gap per wave step — 2 % of a C2 frame).  Every workgroup's counter updates are atomics at agent scope and come before its
 // ticket (release fence); the last ticket holder reads them with atomic loads behind an acquire fence.
-template <bool kCamera, bool kTex>
+template <bool kCamera, bool kTex, bool kFused = false>
 __global__ void __launch_bounds__(kShadeBlock, BHRT_SHADE_WAVES) k_shade(DevScene S, RenderParams R, PassInfo P, RayQueue qin, HitBuf hb, uint32_t n, RayQueue qout,
                                                    ShadowQueue qs, Frames F, float *samples, Counters *cnt, RayOrder ord, HostCounters *pub, uint32_t seq)
 {
-    shade_block<kCamera, kTex>(S, R, P, qin, hb, n, qout, qs, F, samples, cnt, ord);
+    shade_block<kCamera, kTex, kFused>(S, R, P, qin, hb, n, qout, qs, F, samples, cnt, ord);
     if (!pub) return;
     __syncthreads(); // every wave is through: its queue counters were added to by returning atomics whose results it has used (block_alloc), its
     // capacity flags likewise (flag_overflow) — all acknowledged.  No agent-scope fence: only counters travel, all by atomics at agent scope; a release
@@ -2067,7 +2082,11 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 injected = true;
             }
             const SlowQueue &sq = slowq;
-            if (injected) {
+            // the camera step of a scene without meshes: k_shade traces its rays itself (shade_block's kFused); BHRT_FUSED_CAMERA=0: the two-kernel form
+            static const bool fuse_camera = !getenv("BHRT_FUSED_CAMERA") || atoi(getenv("BHRT_FUSED_CAMERA")) != 0;
+            const bool fused = first_step && H->n_meshes == 0 && fuse_camera;
+            if (fused) {
+            } else if (injected) {
                 Timer t(D, &st->seconds_trace_closest);
                 hipLaunchKernelGGL(k_file_all, dim3((n_cur + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, Q[cur], HB, n_cur, RO, D->d_cnt);
                 t.Stop();
@@ -2102,14 +2121,17 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, false, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt, no_slow);
                 t.Stop();
             }
-            st->launches_trace_closest++;
-            hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(128), 0, D->stream, D->d_cnt, RO);
+            if (!fused) {
+                st->launches_trace_closest++;
+                hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(128), 0, D->stream, D->d_cnt, RO);
+            }
             const uint32_t seq = ++D->pub_seq;
             {
                 Timer t(D, &st->seconds_shade, 0);
-                const dim3 sg((n_cur + kShadeBlock - 1) / kShadeBlock + 3 * BHRT_ORDER_SHARDS), sb(kShadeBlock);
+                const dim3 sg((n_cur + kShadeBlock - 1) / kShadeBlock + (fused ? 0 : 3 * BHRT_ORDER_SHARDS)), sb(kShadeBlock);
                 const bool tex = H->n_texmaps > 0;
-                auto shade = first_step ? (tex ? k_shade<true, true> : k_shade<true, false>) : (tex ? k_shade<false, true> : k_shade<false, false>);
+                auto shade = fused ? (tex ? k_shade<true, true, true> : k_shade<true, false, true>)
+                                   : first_step ? (tex ? k_shade<true, true> : k_shade<true, false>) : (tex ? k_shade<false, true> : k_shade<false, false>);
                 hipLaunchKernelGGL(shade, sg, sb, 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt, RO, D->d_pub, seq); // + n_next, n_shadow, n_frames, overflow to the host
                 t.Stop();
             }
