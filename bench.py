@@ -209,7 +209,7 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
                "k_shade": agg["seconds_shade"], "k_photon_gather": gather_s, "other": agg["seconds_other"]}
     units = {"k_trace_closest": (agg["closest_rays"], BYTES_PER_CLOSEST_RAY, agg["launches_trace_closest"]),
              "k_trace_shadow": (agg["shadow_rays"], BYTES_PER_SHADOW_RAY, agg["launches_trace_shadow"]),
-             "k_shade": (agg["closest_rays"], BYTES_PER_SHADE_VERTEX, agg["launches_trace_closest"]),
+             "k_shade": (agg["closest_rays"], BYTES_PER_SHADE_VERTEX, agg["wave_iterations"]),  # one k_shade per wave step (the camera step of a mesh-free scene has no trace kernel of its own)
              "k_photon_gather": (agg.get("photon_nodes_visited", 0), BYTES_PER_PHOTON_VISITED, max(1, agg["passes"]))}
     dom = max(units, key=lambda k: k_times[k])
     n_units, bpu, launches = units[dom]
