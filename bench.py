@@ -196,7 +196,7 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
         rays_total, closest_total, samples_total = (float(x) for x in rr.tolist())
     else:
         rays_total, closest_total, samples_total = float(rays_local), float(agg["closest_rays"]), float(agg["camera_samples"])
-    sc.close()  # frees this workload's HBM (scene + up to ~65 GB of wavefront workspace) before the next one
+    sc.close()  # frees this workload's HBM (scene + up to ~190 GB of wavefront workspace) before the next one
     del bufs
     torch.cuda.empty_cache()
     if rank != 0:

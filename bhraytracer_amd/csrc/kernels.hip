@@ -1739,6 +1739,20 @@ static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, uint32_t frames
     return BHRT_OK;
 }
 
+// The largest power of two of camera samples in flight (<= 2^27) whose wavefront buffers fit into 85 % of what the device has free, the present
+// workspace counted as free (EnsureWorkspace releases it before it allocates).  Per sample: two ray slots in two queues (72 B each), their hit
+// (16 B) and shadow (32 B) slots, shading order and park lists (40 B per ray slot), six frames (116 B each, + 60 B with the photon map), 12 B of radiance.
+static uint32_t DefaultPassSamples(DeviceState *D, bool photon_map)
+{
+    const size_t per_sample = 2 * (2 * 72 + 16 + 32 + 40) + 6 * (116 + (photon_map ? 60 : 0)) + 12;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 1u << 26;
+    const size_t have = (size_t)D->cap_samples * per_sample;
+    for (uint32_t p = 1u << 27; p > (1u << 22); p >>= 1)
+        if (D->cap_samples >= p || (size_t)p * per_sample <= (size_t)(0.85 * (double)(free_b + have))) return p;
+    return 1u << 22;
+}
+
 static Frames MakeFrames(DeviceState *D)
 {
     Frames F;
@@ -1988,9 +2002,11 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
     const uint32_t owned_tiles = n_tiles > (uint32_t)o.rank ? (n_tiles - (uint32_t)o.rank + (uint32_t)world - 1) / (uint32_t)world : 0;
     const uint64_t owned_pixels = (uint64_t)owned_tiles * tile * tile;
 
-    // Sized for 288 GB of HBM: few, large passes (every pass ends in a tail of nearly empty wavefront steps, so fewer passes = fewer
-    // tails).  ~1 KB of wavefront state per camera sample -> the default of 2^26 samples in flight takes ~65 GB.
-    uint32_t pass_samples = o.samples_per_pass > 0 ? (uint32_t)o.samples_per_pass : (1u << 26);
+    // Sized for 288 GB of HBM: few, large passes (every pass ends in a tail of nearly empty wavefront steps, and the big launches of a pass's
+    // first steps run the denser the more rays they hold: ONE pass of 1.3e8 samples instead of two of 6.6e7 takes 7-9 % off the C3 and closed-room
+    // frames).  ~1 KB of wavefront state per camera sample (1.4 KB with the photon-map frames) -> the default of 2^27 samples in flight takes
+    // ~138 GB (186 GB); with less memory free the default halves until it fits.
+    uint32_t pass_samples = o.samples_per_pass > 0 ? (uint32_t)o.samples_per_pass : DefaultPassSamples(D, o.photon_map != 0);
     pass_samples = (uint32_t)std::min<uint64_t>(pass_samples, std::max<uint64_t>(owned_pixels * (uint64_t)o.spp, 1)); // never more than this render needs
     if (pass_samples < (uint32_t)o.spp) pass_samples = (uint32_t)o.spp;
     const uint32_t frames_per_sample = 6; // Shade() frames per camera sample; an overflow halves the pass and retries

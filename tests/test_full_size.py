@@ -97,7 +97,7 @@ def test_c4_one_rank_at_the_real_256_spp(gpu, load_scene, O):
     t = next(t for t in range(tiles_x * (2160 // tile + 1) - 1, 0, -1) if t % world == rank and t // tiles_x == 60 and 40 <= t % tiles_x <= 60)
     x0, y0 = (t % tiles_x) * tile, (t // tiles_x) * tile
     region = (x0, y0, x0 + 32, y0 + 16)
-    opts = gpu.default_opts(spp=spp, gi_bounces=3, seed=0, rank=rank, world_size=world, tile_size=tile)
+    opts = gpu.default_opts(spp=spp, gi_bounces=3, seed=0, rank=rank, world_size=world, tile_size=tile, samples_per_pass=1 << 26)
     gs, st = sc.render_samples(opts, *region)
     assert st.passes >= 4 and st.camera_samples == 1036800 * spp
     ro = O.render(sc.flat_bytes(), sc.width, sc.height, spp, gi=3, seed=0, region=region, threads=16)
