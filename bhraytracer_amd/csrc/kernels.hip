@@ -419,6 +419,9 @@ constexpr int kStreamRefill = BHRT_STREAM_REFILL;
 #ifndef BHRT_STREAM_OCC
 #define BHRT_STREAM_OCC 6 /* waves per SIMD the streaming kernels are compiled for */
 #endif
+#ifdef BHRT_DEBUG_DRAIN
+__device__ unsigned long long g_stream_t[4]; // wall clock (100 MHz): first wave in, first wave that found the list exhausted, last wave out
+#endif
 #ifdef BHRT_DEBUG_STREAM
 __device__ unsigned long long g_stream_dbg[8]; // rounds, lanes with a walk, lanes in the round's phase, clocks in rounds, clocks outside, refills, descend / leaf rounds
 #endif
@@ -441,6 +444,10 @@ __global__ void __launch_bounds__(64, BHRT_STREAM_OCC) k_trace_mesh_stream(DevSc
 #ifdef BHRT_DEBUG_STREAM
     unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long c_mark = __builtin_readcyclecounter();
+#endif
+#ifdef BHRT_DEBUG_DRAIN
+    if (lane == 0) atomicMin(&g_stream_t[0], wall_clock64());
+    bool told = false;
 #endif
     for (;;) {
         // (1) lanes through with their mesh: the rest of the scene graph (trace_closest's node loop from n + 1)
@@ -475,6 +482,10 @@ __global__ void __launch_bounds__(64, BHRT_STREAM_OCC) k_trace_mesh_stream(DevSc
                 exhausted = base + n_idle >= total;
 #ifdef BHRT_DEBUG_STREAM
                 dbg[5]++;
+#endif
+#ifdef BHRT_DEBUG_DRAIN
+                if (exhausted && !told && lane == 0) { atomicMin(&g_stream_t[1], wall_clock64()); }
+                told = told || exhausted;
 #endif
                 const uint32_t k = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 if (!have && k < total) {
@@ -534,6 +545,9 @@ __global__ void __launch_bounds__(64, BHRT_STREAM_OCC) k_trace_mesh_stream(DevSc
     }
 #ifdef BHRT_DEBUG_STREAM
     if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_stream_dbg[k], dbg[k]);
+#endif
+#ifdef BHRT_DEBUG_DRAIN
+    if (lane == 0) atomicMax(&g_stream_t[2], wall_clock64());
 #endif
 }
 // Files the finished mesh rays of a later wave step under their shading class, walking the parked list as it was filed
@@ -2127,8 +2141,20 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                     auto mesh_kernel = first_step ? (path_mode == 1 ? k_trace_mesh<true, 1> : path_mode == 2 ? k_trace_mesh<true, 2> : k_trace_mesh<true, 0>)
                                                   : (path_mode == 1 ? k_trace_mesh<false, 1> : path_mode == 2 ? k_trace_mesh<false, 2> : k_trace_mesh<false, 0>);
                     if (!first_step && path_mode != 0 && stream_waves > 0)
+                    {
+#ifdef BHRT_DEBUG_DRAIN
+                        { unsigned long long t0[4] = {~0ull, ~0ull, 0, 0}; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stream_t), t0, sizeof(t0))); }
+#endif
                         hipLaunchKernelGGL(path_mode == 1 ? k_trace_mesh_stream<1> : k_trace_mesh_stream<2>, dim3(std::min<uint32_t>((n_cur + 63) / 64, stream_waves)), dim3(64), 0, D->stream, D->S,
                                            Q[cur], HB, RO, D->d_cnt);
+#ifdef BHRT_DEBUG_DRAIN
+                        unsigned long long t1[4];
+                        HIP_CHECK(hipMemcpyFromSymbol(t1, HIP_SYMBOL(g_stream_t), sizeof(t1)));
+                        static double dbg_total = 0, dbg_drain = 0;
+                        if (t1[1] != ~0ull) { dbg_total += (double)(t1[2] - t1[0]) / 1e5; dbg_drain += (double)(t1[2] - t1[1]) / 1e5; }
+                        if (getenv("BHRT_DEBUG_DRAIN")) fprintf(stderr, "mesh launch: %u rays, %.3f ms, of which %.3f ms after the list ran out (sums %.1f / %.1f ms)\n", n_cur, (double)(t1[2] - t1[0]) / 1e5, t1[1] != ~0ull ? (double)(t1[2] - t1[1]) / 1e5 : 0.0, dbg_total, dbg_drain);
+#endif
+                    }
                     else
                     hipLaunchKernelGGL(mesh_kernel, first_step ? dim3(tg.x + BHRT_ORDER_SHARDS) /* shard segments padded to whole slices */ : dim3((n_cur + kMeshBlock - 1) / kMeshBlock),
                                        first_step ? tb : dim3(kMeshBlock), 0, D->stream, D->S, P, Q[cur], HB, RO, D->d_cnt);
