@@ -48,14 +48,15 @@ def unpack_tiles(allb: torch.Tensor, width: int, height: int, tile: int) -> torc
     return img[:height, :width]
 
 
-def gather_frame_dev(rgb8: torch.Tensor, radiance: torch.Tensor, tile: int, rank: int, world: int, group=None, scratch=None, via_host=False):
+def gather_frame_dev(rgb8: torch.Tensor, radiance: torch.Tensor, tile: int, rank: int, world: int, group=None, scratch=None, via_host=False, force=False):
     """GPU path of the exchange: native pack (bhrt_tiles_pack_dev) -> ONE all_gather of byte blocks -> native unpack
     into the same (H, W, 3) uint8 / float32 device tensors, in place.  `scratch`: dict reused across frames.
     via_host: move the blocks through host memory and a CPU backend (rehearsal of N ranks on one GPU, where RCCL
-    cannot run); pack and unpack still run on the device."""
+    cannot run); pack and unpack still run on the device.  force: go through pack / all_gather / unpack even in a world of one (tests: the RCCL
+    calls of this path on a one-GPU box)."""
     import torch.distributed as dist
     import bhraytracer_amd as B
-    if world == 1:
+    if world == 1 and not force:
         return
     H, W, _ = rgb8.shape
     bb = B.tiles_block_bytes(W, H, tile, world)

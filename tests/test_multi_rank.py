@@ -81,3 +81,42 @@ def test_bench_gpus_2_starts_its_own_ranks():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "2 spp (1 per GPU)" in d["config"]["workload"] and d["value"] > 0
+
+
+_RCCL_WORLD_OF_ONE = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+import bhraytracer_amd as B, bhraytracer_amd.dist as BD
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str({port})
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+sc = B.Scene({scene!r}); sc.upload(0)
+H, W = sc.height, sc.width
+rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev); rad = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+opts = B.default_opts(spp=2, gi_bounces=2, seed=4)
+sc.render_dev(opts, rgb.data_ptr(), rad.data_ptr())
+torch.cuda.synchronize()
+rgb0, rad0 = rgb.clone(), rad.clone()
+BD.gather_frame_dev(rgb, rad, 32, 0, 1, force=True)            # pack -> RCCL all_gather_into_tensor -> unpack, in place
+torch.cuda.synchronize()
+assert torch.equal(rgb, rgb0) and torch.equal(rad.view(torch.int32), rad0.view(torch.int32)), "frame changed by the exchange"
+# the collectives photon_build_sharded issues, on device tensors
+sizes = torch.zeros(1, dtype=torch.int64, device=dev); sizes[0] = 12345
+dist.all_reduce(sizes); assert int(sizes.cpu()[0]) == 12345
+buf = torch.arange(24 * 1000, dtype=torch.int32, device=dev).to(torch.uint8).reshape(1000, 24)
+allb = torch.empty_like(buf); dist.all_gather_into_tensor(allb, buf); assert torch.equal(allb, buf)
+dist.barrier(); dist.destroy_process_group()
+print("rccl world of one: ok")
+"""
+
+
+@pytest.mark.gpu
+def test_the_rccl_calls_of_the_exchange_in_a_world_of_one(tmp_path):
+    """Multi-GPU runs are not ours to launch; what a one-GPU box can show is that the RCCL calls the N > 1 path makes — process group on a
+    device, all_gather_into_tensor of the packed byte blocks between the native pack and unpack kernels on torch's stream, the int64
+    all_reduce and the (n, 24) uint8 all_gather of the sharded photon build — run on device tensors and leave the frame as it was."""
+    import subprocess
+    code = _RCCL_WORLD_OF_ONE.format(root=ROOT, port=29700 + os.getpid() % 1000, scene=os.path.join(SCENES, "c2_glass_small.xml"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl world of one: ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
