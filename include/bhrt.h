@@ -65,7 +65,8 @@ typedef struct bhrt_opts {
     /* tile partition: this process renders tiles t with t % world_size == rank */
     int32_t rank, world_size;
     int32_t tile_size;        /* square tile edge in pixels, default 32 */
-    int32_t samples_per_pass; /* 0 = choose; upper bound on camera samples in flight per wavefront pass */
+    int32_t samples_per_pass; /* upper bound on camera samples in flight per wavefront pass (~1 KB of device memory each, 1.4 KB with the photon map);
+                                 0 = choose: what the frame needs, at most 2^27 (~138 GB / 186 GB), halved until it fits into 85 % of the free memory */
     int32_t timers;           /* HIP-event kernel timers of bhrt_stats: 0 = seconds_shade only (default; an event between two kernels
                                * idles the GPU ~6 us), 1 = all kernel groups, -1 = none */
     int32_t photon_exact;     /* caustic gather of queries with >= 1000 photons inside the radius: 0 (default) = the same photon SET as
