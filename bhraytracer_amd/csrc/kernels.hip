@@ -1677,6 +1677,8 @@ struct DeviceState {
     // a capacity overflow halves the pass (RenderRange); later frames of the same scene and options start from the reduced size
     uint64_t pass_hint_key = 0;
     uint32_t pass_hint = 0;
+    uint64_t frames_seen_key = 0; // Shade() frames per sample slot the passes of a render (scene, options: the key) have needed so far (max)
+    double frames_seen = 0;
     // bhrt_render: the device copy of the frame, kept between calls
     uint8_t *d_frame_rgb = nullptr;
     float *d_frame_rad = nullptr;
@@ -1721,16 +1723,18 @@ static int EnsureUploaded(bhrt_scene *scene)
     return bhrt_scene_upload(scene, 0);
 }
 
-static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, uint32_t frames_per_sample)
+static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, double frames_per_sample)
 {
-    if (D->cap_samples >= cap_samples && D->cap_frames >= cap_samples * frames_per_sample) return BHRT_OK;
+    const size_t cf_wanted = (size_t)std::ceil((double)cap_samples * frames_per_sample);
+    if (cf_wanted > 0xffffffffull) { SetError("frame pool beyond 2^32 frames"); return BHRT_ERR_ARG; }
+    if (D->cap_samples >= cap_samples && D->cap_frames >= cf_wanted) return BHRT_OK;
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     for (int k = 0; k < 2; k++) { fr(D->d_rayf[k]); fr(D->d_rayu[k]); D->d_rayf[k] = nullptr; D->d_rayu[k] = nullptr; }
     fr(D->d_hitf); fr(D->d_hiti); fr(D->d_shf); fr(D->d_shu); fr(D->d_fu); fr(D->d_fcode); fr(D->d_ff); fr(D->d_samples); fr(D->d_order); fr(D->d_park);
     D->d_order = nullptr; D->d_park = nullptr;
     D->d_hitf = nullptr; D->d_hiti = nullptr; D->d_shf = nullptr; D->d_shu = nullptr; D->d_fu = nullptr; D->d_fcode = nullptr; D->d_ff = nullptr; D->d_samples = nullptr;
     D->cap_samples = 0;
-    const size_t cr = (size_t)cap_samples * 2, cf = (size_t)cap_samples * frames_per_sample;
+    const size_t cr = (size_t)cap_samples * 2, cf = cf_wanted;
     for (int k = 0; k < 2; k++) {
         HIP_CHECK(hipMalloc(&D->d_rayf[k], cr * 6 * sizeof(float)));
         HIP_CHECK(hipMalloc(&D->d_rayu[k], cr * 3 * sizeof(uint32_t)));
@@ -1753,17 +1757,19 @@ static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, uint32_t frames
     return BHRT_OK;
 }
 
-// The largest power of two of camera samples in flight (<= 2^27) whose wavefront buffers fit into 85 % of what the device has free, the present
-// workspace counted as free (EnsureWorkspace releases it before it allocates).  Per sample: two ray slots in two queues (72 B each), their hit
-// (16 B) and shadow (32 B) slots, shading order and park lists (40 B per ray slot), six frames (116 B each, + 60 B with the photon map), 12 B of radiance.
-static uint32_t DefaultPassSamples(DeviceState *D, bool photon_map)
+// The largest power of two of camera samples in flight (<= 2^28) whose wavefront buffers fit into 85 % of what the device has free, the present
+// workspace counted as free (EnsureWorkspace releases it before it allocates).  Per sample: two ray slots (72 B each: 36 B in each of the two
+// queues), their hit (16 B) and shadow (32 B) slots, shading order and park lists (40 B per ray slot), 12 B of radiance, and `frames_per_sample`
+// Shade() frames (116 B each, + 60 B with the photon map): six by default = 1.03 KB per sample, 2^27 samples = 138 GB.
+static uint32_t DefaultPassSamples(DeviceState *D, bool photon_map, double frames_per_sample)
 {
-    const size_t per_sample = 2 * (2 * 72 + 16 + 32 + 40) + 6 * (116 + (photon_map ? 60 : 0)) + 12;
+    const double frame_b = 116 + (photon_map ? 60 : 0);
+    const double per_sample = 2 * (72 + 16 + 32 + 40) + 12 + frames_per_sample * frame_b;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 1u << 26;
-    const size_t have = (size_t)D->cap_samples * per_sample;
-    for (uint32_t p = 1u << 27; p > (1u << 22); p >>= 1)
-        if (D->cap_samples >= p || (size_t)p * per_sample <= (size_t)(0.85 * (double)(free_b + have))) return p;
+    const double have = (double)D->cap_samples * (2 * (72 + 16 + 32 + 40) + 12) + (double)D->cap_frames * frame_b;
+    for (uint32_t p = 1u << 28; p > (1u << 22); p >>= 1)
+        if ((D->cap_samples >= p && (double)D->cap_frames >= (double)p * frames_per_sample) || (double)p * per_sample <= 0.85 * ((double)free_b + have)) return p;
     return 1u << 22;
 }
 
@@ -2020,10 +2026,21 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
     // first steps run the denser the more rays they hold: ONE pass of 1.3e8 samples instead of two of 6.6e7 takes 7-9 % off the C3 and closed-room
     // frames).  ~1 KB of wavefront state per camera sample (1.4 KB with the photon-map frames) -> the default of 2^27 samples in flight takes
     // ~138 GB (186 GB); with less memory free the default halves until it fits.
-    uint32_t pass_samples = o.samples_per_pass > 0 ? (uint32_t)o.samples_per_pass : DefaultPassSamples(D, o.photon_map != 0);
+    // Shade() frames per sample slot: six are provided for (an overflow halves the pass and redoes it).  A frame that does not fit into one pass
+    // with six — C4's 2.7e8 samples per GPU — takes what the earlier passes of the same render (scene, options) have needed, + 30 %: C4 needs 1.1
+    // frames per sample, and with 1.7 provided its 2^28 slots fit into 180 GB: one pass per frame instead of two.
+    const uint64_t frames_key = ((uint64_t)(uint32_t)o.spp << 48) ^ ((uint64_t)(uint32_t)(o.gi_bounces + 1) << 40) ^ ((uint64_t)(uint32_t)o.internal_bounces << 32) ^
+                                ((uint64_t)(uint32_t)world << 24) ^ ((uint64_t)(uint32_t)tile << 8) ^ (uint64_t)(o.photon_map ? 1 : 0);
+    double frames_per_sample = 6.0;
+    bool frames_learned = false;
+    if (o.samples_per_pass <= 0 && D->frames_seen_key == frames_key && D->frames_seen > 0 && D->frames_seen < 4.0 &&
+        owned_pixels * (uint64_t)o.spp > DefaultPassSamples(D, o.photon_map != 0, 6.0)) {
+        frames_per_sample = std::min(6.0, D->frames_seen * 1.3 + 0.25);
+        frames_learned = true;
+    }
+    uint32_t pass_samples = o.samples_per_pass > 0 ? (uint32_t)o.samples_per_pass : DefaultPassSamples(D, o.photon_map != 0, frames_per_sample);
     pass_samples = (uint32_t)std::min<uint64_t>(pass_samples, std::max<uint64_t>(owned_pixels * (uint64_t)o.spp, 1)); // never more than this render needs
     if (pass_samples < (uint32_t)o.spp) pass_samples = (uint32_t)o.spp;
-    const uint32_t frames_per_sample = 6; // Shade() frames per camera sample; an overflow halves the pass and retries
     D->timers = o.timers;
     D->photon_exact = o.photon_exact;
     int path_mode = 1; // the traversal's path in LDS: 1 = 16-bit pair indices, 2 = 32-bit (a mesh with 2^17 nodes or more), 0 = no (deeper than 32 levels)
@@ -2221,6 +2238,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             if (pass_limit <= (uint32_t)o.spp) { SetError("wavefront buffers overflow even with one pixel per pass"); return BHRT_ERR_OVERFLOW; }
             pass_limit = std::max<uint32_t>((uint32_t)o.spp, pass_limit / 2);
             D->pass_hint_key = hint_key; D->pass_hint = pass_limit;
+            if (frames_learned) D->frames_seen = 6.0; // the smaller frame pool was not enough after all: the next render of this kind provides six again
             continue;
         }
 #ifdef BHRT_DEBUG_STREAM
@@ -2239,6 +2257,11 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         }
 #endif
         st->camera_samples += pass_camera; st->shadow_rays += pass_shadow; st->wave_iterations += pass_steps; st->deferred_rays += pass_deferred;
+        { // what this pass needed of its frame pool, per sample slot
+            const double seen = (double)frame_marks.back() / (double)std::max<uint64_t>((uint64_t)npx * (uint64_t)o.spp, 1);
+            if (D->frames_seen_key != frames_key) { D->frames_seen_key = frames_key; D->frames_seen = 0; }
+            D->frames_seen = std::max(D->frames_seen, seen);
+        }
         if (o.photon_map && frame_marks.back() > 0) {
             // caustic term (MtlBlinn.cpp:329-342) of every frame of the pass in ONE gather: a gather launch lasts as long as its
             // longest query (15-80 ms for a query that fills the 1000-candidate heap), so a gather per wave step — 23 steps
