@@ -113,6 +113,24 @@ def test_c4_one_rank_at_the_real_256_spp(gpu, load_scene, O):
     assert not gs2.any()
 
 
+def test_c4_frame_larger_than_one_pass_sizes_its_frame_pool_from_the_first_frame(gpu):
+    """BASELINE config 4 per GPU: 3840x2160 x 32 spp = 2.65e8 sample slots do not fit into one pass with six Shade() frames per slot; the first
+    frame runs in two passes and notes what they needed (1.1 frames per slot), the second provides that + 30 % and — memory permitting: other
+    scenes of this test session hold workspaces too — runs in one pass.  Same frame, byte for byte."""
+    import os
+    sc = gpu.Scene(os.path.join(SCENES, "c4_mesh_4k.xml"))
+    try:
+        opts = gpu.default_opts(spp=32, gi_bounces=3, seed=2)
+        rgb1, rad1, st1 = sc.render(opts)
+        assert st1.camera_samples == 3840 * 2160 * 32 and st1.passes >= 2
+        rgb2, rad2, st2 = sc.render(opts)
+        assert st2.passes <= st1.passes
+        assert np.array_equal(rgb1, rgb2) and same_bits(rad1, rad2)
+        assert (st2.closest_rays, st2.shadow_rays, st2.shade_calls) == (st1.closest_rays, st1.shadow_rays, st1.shade_calls)
+    finally:
+        sc.close()
+
+
 # ---------------------------------------------------------------------------------------------------- closed-room mesh workload
 def test_c3_room_primary_hits_vs_reference(gpu, load_scene, golden, O):
     sc = load_scene("c3_room")
