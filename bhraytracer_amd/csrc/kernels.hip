@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, PassInfo P
 }
 // Slice `b` (kBlock entries) of the parked list RC_MESH (32 shard segments, each padded to whole slices; table by
 // k_mesh_prefix).  Called by a whole workgroup; false = b is beyond the last slice (uniform).
-__device__ inline bool parked_entry(const RayOrder &ord, uint32_t b, uint32_t *s_seg, uint32_t &i)
+__device__ inline bool parked_entry(const RayOrder &ord, uint32_t b, uint32_t *s_seg, uint32_t &i, uint32_t first_entry = 0 /* of the slice: a workgroup narrower than kBlock takes part of one */)
 {
     __syncthreads(); // *s_seg of the previous slice no longer in use
     if (threadIdx.x < 64) {
@@ -318,7 +318,7 @@ __device__ inline bool parked_entry(const RayOrder &ord, uint32_t b, uint32_t *s
     __syncthreads();
     if (b >= ord.mesh_start[BHRT_ORDER_SHARDS]) return false;
     const uint32_t seg = *s_seg;
-    const uint32_t local = (b - ord.mesh_start[seg]) * kBlock + threadIdx.x;
+    const uint32_t local = (b - ord.mesh_start[seg]) * kBlock + first_entry + threadIdx.x;
     const bool active = local < ord.mesh_count[seg];
     i = active ? ord.idx[((size_t)RC_MESH * BHRT_ORDER_SHARDS + seg) * ord.shard_cap + local] : 0xffffffffu;
     return true;
@@ -630,17 +630,22 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow_park(DevScene S, Shadow
     }
     file_ray(v == 2.f ? (uint32_t)RC_MESH : (uint32_t)RC_NONE, i, (i >> 10) & (BHRT_ORDER_SHARDS - 1), ord, cnt);
 }
+#ifndef BHRT_SHADOW_BLOCK
+#define BHRT_SHADOW_BLOCK 64 /* threads per workgroup of k_shadow_mesh (a divisor of kBlock): a wave leaves as soon as its own rays are done (256: any-hit group +6-7 % on C3 and the closed room) */
+#endif
+constexpr int kShadowBlock = BHRT_SHADOW_BLOCK;
 template <int kPath> // kPath: traversal path in LDS (mesh_shadow_stack), same modes as k_trace_mesh
-__global__ void __launch_bounds__(kBlock) k_shadow_mesh(DevScene S, ShadowQueue q, float *vis, RayOrder ord)
+__global__ void __launch_bounds__(kShadowBlock) k_shadow_mesh(DevScene S, ShadowQueue q, float *vis, RayOrder ord)
 {
     typedef typename std::conditional<kPath == 2, uint32_t, uint16_t>::type PathT;
     __shared__ uint32_t s_seg;
-    __shared__ PathT path[kPath ? 33 * kBlock : 1];
+    __shared__ PathT path[kPath ? 33 * kShadowBlock : 1];
+    constexpr uint32_t kParts = kBlock / kShadowBlock; // workgroups per slice of kBlock entries
     uint32_t i, slice;
-    if (!xcd_slice(blockIdx.x, ord.mesh_start[BHRT_ORDER_SHARDS], slice)) return;
-    if (!parked_entry(ord, slice, &s_seg, i)) return;
+    if (!xcd_slice(blockIdx.x / kParts, ord.mesh_start[BHRT_ORDER_SHARDS], slice)) return;
+    if (!parked_entry(ord, slice, &s_seg, i, (blockIdx.x % kParts) * kShadowBlock)) return;
     if (i == 0xffffffffu) return;
-    vis[q.frame[i]] = trace_shadow_t<2, PathT>(S, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), q.tmax[i], kPath ? path + threadIdx.x : (PathT *)nullptr, kBlock);
+    vis[q.frame[i]] = trace_shadow_t<2, PathT>(S, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), q.tmax[i], kPath ? path + threadIdx.x : (PathT *)nullptr, kShadowBlock);
 }
 
 // segment table of the parked mesh rays for k_trace_mesh: 32 shards, one lane each
@@ -2203,7 +2208,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                     hipLaunchKernelGGL(k_trace_shadow_park, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis, RO, D->d_cnt);
                     hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
                     // (streamed like k_trace_mesh_stream the any-hit walks gain nothing: they are short, C4 +4 ms, closed room -2 ms)
-                    hipLaunchKernelGGL(path_mode == 1 ? k_shadow_mesh<1> : path_mode == 2 ? k_shadow_mesh<2> : k_shadow_mesh<0>, dim3(hg.x + BHRT_ORDER_SHARDS), hb, 0, D->stream, D->S, SQ, F.vis, RO);
+                    hipLaunchKernelGGL(path_mode == 1 ? k_shadow_mesh<1> : path_mode == 2 ? k_shadow_mesh<2> : k_shadow_mesh<0>, dim3((hg.x + BHRT_ORDER_SHARDS) * (kBlock / kShadowBlock)), dim3(kShadowBlock), 0, D->stream, D->S, SQ, F.vis, RO);
                 } else hipLaunchKernelGGL(k_trace_shadow<false>, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis);
                 t.Stop();
             }
