@@ -207,6 +207,17 @@ __device__ inline int order_fast(float tmin1, float tmin2)
     const float d = tmin2 - tmin1, tol = fmaf(BHRT_FAST_REL, fabsf(tmin1) + fabsf(tmin2), BHRT_FAST_ABS);
     return fabsf(d) > tol ? (d > 0 ? 1 : 0) : -1;
 }
+// Box::IntersectRay's decision for ONE box (a mesh's root box: the gate of TriObj::IntersectRay / ShadowRecursive), approximate first: the
+// three double reciprocals of the exact form (ray_rcp, ~100 instructions) are only formed when the approximation cannot tell.  t_min: the
+// approximate entry distance in that case (the parking kernel's sort key is made of it: an ordering hint), the exact one otherwise.
+template <bool kAsm = true>
+__device__ inline bool box_hit_lazy(const float *b, V3 o, V3 d, const RayRcpF &rf, float t_max, float &t_min)
+{
+    int f = -1;
+    if (!rf.slow) f = kAsm ? box_fast(b, o, rf, t_max, t_min) : box_fast_f(b, o, rf, t_max);
+    if (f < 0) return box_hit_rcp<kAsm>(b, o, d, ray_rcp(d), t_max, t_min);
+    return f == 1;
+}
 
 // barycentric part of IntersectTriangle (TriObj.cpp:105-168), shared with the attribute recomputation; the vertices come
 // projected (bhrt_tri), only the hit point is projected here
@@ -620,8 +631,8 @@ __device__ inline void walk_begin(const MeshRef &M, MeshWalk &W, V3 o, V3 d, flo
     W.o = o; W.d = d;
     W.st = 3;
     W.data = root.data;
-    if (box_hit_rcp(root.b, o, d, ray_rcp(d), ht, tm)) W.st = (W.data & 0x80000000u) ? 1 : 0;
     W.rf = ray_rcp_f(d);
+    if (box_hit_lazy(root.b, o, d, W.rf, ht, tm)) W.st = (W.data & 0x80000000u) ? 1 : 0;
     W.dlen = length(d);
     W.depth = 0;
     W.inFar = 0; W.nearHit = 0; W.sides = 0;
@@ -788,13 +799,12 @@ template <class PathT>
 __device__ inline bool mesh_shadow_stack(const MeshRef &M, V3 o, V3 d, float t_max, PathT *stack, uint32_t stride)
 {
     float tm;
-    const RayRcp rr = ray_rcp(d);
+    const RayRcpF rf = ray_rcp_f(d);
     const NodeRec root = node_at(M, 1);
     int st = 3; // 0 inner node, 1 leaf, 2 climb, 3 done — the wave runs the phase most of its lanes wait for (see mesh_closest_vote)
     uint32_t data = root.data;
-    if (box_hit_rcp<false>(root.b, o, d, rr, BHRT_BIGFLOAT, tm)) st = (data & 0x80000000u) ? 1 : 0;
+    if (box_hit_lazy<false>(root.b, o, d, rf, BHRT_BIGFLOAT, tm)) st = (data & 0x80000000u) ? 1 : 0;
     const float dlen = length(d);
-    const RayRcpF rf = ray_rcp_f(d);
     uint32_t inSecond = 0;
     int depth = 0;
     bool found = false;
@@ -808,8 +818,11 @@ __device__ inline bool mesh_shadow_stack(const MeshRef &M, V3 o, V3 d, float t_m
                 float t1, t2;
                 const NodeRec n1 = node_at(M, c1), n2 = node_at(M, c1 + 1);
                 int f1 = rf.slow ? -1 : box_fast_f(n1.b, o, rf, BHRT_BIGFLOAT), f2 = rf.slow ? -1 : box_fast_f(n2.b, o, rf, BHRT_BIGFLOAT);
-                if (f1 < 0) f1 = box_hit_rcp<false>(n1.b, o, d, rr, BHRT_BIGFLOAT, t1) ? 1 : 0;
-                if (f2 < 0) f2 = box_hit_rcp<false>(n2.b, o, d, rr, BHRT_BIGFLOAT, t2) ? 1 : 0;
+                if (f1 < 0 || f2 < 0) { // the exact form: its double reciprocals only here (kept across the loop they cost twelve registers)
+                    const RayRcp rr = ray_rcp(d);
+                    if (f1 < 0) f1 = box_hit_rcp<false>(n1.b, o, d, rr, BHRT_BIGFLOAT, t1) ? 1 : 0;
+                    if (f2 < 0) f2 = box_hit_rcp<false>(n2.b, o, d, rr, BHRT_BIGFLOAT, t2) ? 1 : 0;
+                }
                 if (f1 != 1 && f2 != 1) st = 2;
                 else {
                     // TraceBVHShadow visits both children once either box is hit; a box-missed inner child ends at its own two box
@@ -963,7 +976,7 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
         } else if (park) {
             float tm; // the root box gate of TriObj::IntersectRay (TriObj.cpp:17-39), repeated by mesh_closest on resume
             const NodeRec root = node_at(M, 1);
-            if (box_hit_rcp(root.b, lp, ld, ray_rcp(ld), h.t, tm)) {
+            if (box_hit_lazy(root.b, lp, ld, ray_rcp_f(ld), h.t, tm)) {
                 parked = n;
                 if (park_slow) *park_slow = ld.x == 0 || ld.y == 0 || ld.z == 0;
                 if (park_key) { // ordering hint only: any value is correct
@@ -1045,7 +1058,7 @@ __device__ inline float trace_shadow_t(const DevScene &S, V3 o, V3 d, float t_ma
         } else if (kMode == 3) {
         } else if (kMode == 1) {
             float tm; // the root box gate of TriObj::ShadowRecursive (TriObj.cpp:41-54), repeated by mesh_shadow
-            if (!wants_mesh && box_hit_rcp<false>(node_at(mesh_ref(S, S.nodes[n].mesh), 1).b, lp, ld, ray_rcp(ld), BHRT_BIGFLOAT, tm)) wants_mesh = true;
+            if (!wants_mesh && box_hit_lazy<false>(node_at(mesh_ref(S, S.nodes[n].mesh), 1).b, lp, ld, ray_rcp_f(ld), BHRT_BIGFLOAT, tm)) wants_mesh = true;
         } else {
             if (path ? mesh_shadow_stack(mesh_ref(S, S.nodes[n].mesh), lp, ld, t_max, path, path_stride) : mesh_shadow(mesh_ref(S, S.nodes[n].mesh), lp, ld, t_max)) return 0.f;
         }
