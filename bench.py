@@ -196,6 +196,7 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
         rays_total, closest_total, samples_total = (float(x) for x in rr.tolist())
     else:
         rays_total, closest_total, samples_total = float(rays_local), float(agg["closest_rays"]), float(agg["camera_samples"])
+    sc_n_triangles = sc.info.n_triangles
     sc.close()  # frees this workload's HBM (scene + up to ~190 GB of wavefront workspace) before the next one
     del bufs
     torch.cuda.empty_cache()
@@ -239,6 +240,12 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
                      "valu_issue_frac": prof.get(dom + "_valu_issue_frac"),
                      "note": "scene is cache-resident; traversal/shading are latency- and VALU-issue-bound, not HBM-bound (DESIGN.md 4)"},
     }
+    if dom == "k_shade" and sc_n_triangles == 0 and os.environ.get("BHRT_FUSED_CAMERA", "1") != "0":
+        # The camera step of a mesh-free scene is ONE kernel: k_shade traces its camera rays itself, so the launches timed here also do SURVEY's
+        # closest-hit unit (56 B) for every camera sample.  `frac` above stays the conservative figure (shade vertices only); this one adds them.
+        with_trace = (bpu * n_units + BYTES_PER_CLOSEST_RAY * agg["camera_samples"]) / launches / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        res["roofline"]["achieved_incl_camera_trace"] = with_trace
+        res["roofline"]["frac_incl_camera_trace"] = with_trace / HBM_PEAK_GBPS
     if photon_build_s is not None:
         res["photon"] = {"build_s": photon_build_s, "gather_s_per_frame": gather_s / steps,
                          "heavy_pass_s_per_frame": agg.get("seconds_photon_heavy", 0.0) / steps,
