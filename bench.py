@@ -196,7 +196,7 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
         rays_total, closest_total, samples_total = (float(x) for x in rr.tolist())
     else:
         rays_total, closest_total, samples_total = float(rays_local), float(agg["closest_rays"]), float(agg["camera_samples"])
-    sc_n_triangles = sc.info.n_triangles
+    sc_n_meshes = sc.info.n_meshes
     sc.close()  # frees this workload's HBM (scene + up to ~190 GB of wavefront workspace) before the next one
     del bufs
     torch.cuda.empty_cache()
@@ -208,7 +208,8 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
     gather_s = agg.get("seconds_photon_gather", 0.0)
     k_times = {"k_trace_closest": agg["seconds_trace_closest"], "k_trace_shadow": agg["seconds_trace_shadow"],
                "k_shade": agg["seconds_shade"], "k_photon_gather": gather_s, "other": agg["seconds_other"]}
-    units = {"k_trace_closest": (agg["closest_rays"], BYTES_PER_CLOSEST_RAY, agg["launches_trace_closest"]),
+    fused_camera = sc_n_meshes == 0 and os.environ.get("BHRT_FUSED_CAMERA", "1") != "0"  # the camera rays of a mesh-free scene are traced inside k_shade
+    units = {"k_trace_closest": (agg["closest_rays"] - (agg["camera_samples"] if fused_camera else 0), BYTES_PER_CLOSEST_RAY, agg["launches_trace_closest"]),
              "k_trace_shadow": (agg["shadow_rays"], BYTES_PER_SHADOW_RAY, agg["launches_trace_shadow"]),
              "k_shade": (agg["closest_rays"], BYTES_PER_SHADE_VERTEX, agg["wave_iterations"]),  # one k_shade per wave step (the camera step of a mesh-free scene has no trace kernel of its own)
              "k_photon_gather": (agg.get("photon_nodes_visited", 0), BYTES_PER_PHOTON_VISITED, max(1, agg["passes"]))}
@@ -240,7 +241,7 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
                      "valu_issue_frac": prof.get(dom + "_valu_issue_frac"),
                      "note": "scene is cache-resident; traversal/shading are latency- and VALU-issue-bound, not HBM-bound (DESIGN.md 4)"},
     }
-    if dom == "k_shade" and sc_n_triangles == 0 and os.environ.get("BHRT_FUSED_CAMERA", "1") != "0":
+    if dom == "k_shade" and fused_camera:
         # The camera step of a mesh-free scene is ONE kernel: k_shade traces its camera rays itself, so the launches timed here also do SURVEY's
         # closest-hit unit (56 B) for every camera sample.  `frac` above stays the conservative figure (shade vertices only); this one adds them.
         with_trace = (bpu * n_units + BYTES_PER_CLOSEST_RAY * agg["camera_samples"]) / launches / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
