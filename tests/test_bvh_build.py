@@ -1,9 +1,11 @@
 """cyBVH::Build on the device (DataStructure/cyBVH.h:122-142,242-328).
 
-The host front-end builds the BVH the way the reference does (recursive MeanSplit; pinned by the front-end dumps of
-tests/test_ref_parity.py and the hit tables of tests/golden).  The device build has to give the same tree node for node:
-the test loads every scene twice — host build and device build — and compares the whole flattened scene byte for byte
-(node ids, boxes incl. the sign of zeros, leaf ranges, element order, breadth-first copy, depth)."""
+The device build (bvh_build.hip, level-parallel) has to give the reference's tree node for node.  The checker is the ORACLE's
+restatement of cyBVH::Build (oracle/bhrt_oracle.cpp::oracle_bvh_build, pinned against the compiled reference's own BVH dumps in
+tests/test_ref_parity.py): node ids, boxes incl. the sign of zeros, leaf ranges, parent links and element order of the device build
+are compared with it word for word — for the mesh scenes and for 24 adversarial triangle soups.  The product's own host build
+(scene_host.cpp::BuildBvh, the recursive MeanSplit) is only the second opinion: the whole flattened scene of a host-built and a
+device-built load must be the same bytes (breadth-first copy, leaf-ordered triangle records and depth included)."""
 import os
 
 import numpy as np
@@ -58,20 +60,28 @@ def soups():
 
 
 @pytest.mark.gpu
-def test_device_bvh_equals_host_bvh_on_scenes(B):
-    from conftest import SCENES
+def test_device_bvh_equals_the_oracle_on_scenes(B, O):
+    from conftest import SCENES, ensure_mesh
     if B.device_count() < 1:
         pytest.fail("no HIP device")
-    for name in ("c3_mesh_small", "c3_mesh"):
+    ensure_mesh(224)
+    for name in ("c3_mesh_small", "c3_mesh", "c3_room"):
         path = os.path.join(SCENES, name + ".xml")
-        host, dev = B.Scene(path), B.Scene(path, bvh_device=0)
-        assert host.info.n_bvh_nodes == dev.info.n_bvh_nodes and host.info.max_bvh_depth == dev.info.max_bvh_depth
+        dev = B.Scene(path, bvh_device=0)
+        m = dev.flat_view().mesh_arrays(0)
+        nodes, elems = O.bvh_build(m["v"], m["f"], 4)                        # cyBVH.h:122-142,242-328 restated in oracle/
+        assert nodes.shape[0] == m["bvh_raw"].shape[0] == dev.info.n_bvh_nodes, name
+        assert np.array_equal(nodes[1:], m["bvh_raw"][1:]), name             # bounds, data word and parent link of every node
+        assert np.array_equal(elems, m["elems"]), name
+        dn, de, depth = B.bvh_build(m["v"], m["f"])                          # the bare entry point on the same arrays
+        assert np.array_equal(dn[1:], nodes[1:]) and np.array_equal(de, elems) and depth == dev.info.max_bvh_depth
+        host = B.Scene(path)                                                 # second opinion: the product's host build, whole blob
         assert host.flat_bytes() == dev.flat_bytes(), name
-    assert host.info.n_triangles > 100000
+    assert dev.info.n_triangles > 100000
 
 
 @pytest.mark.gpu
-def test_device_bvh_equals_host_bvh_on_triangle_soups(B, tmp_path):
+def test_device_bvh_equals_the_oracle_on_triangle_soups(B, O, tmp_path):
     if B.device_count() < 1:
         pytest.fail("no HIP device")
     branches = set()
@@ -84,6 +94,10 @@ def test_device_bvh_equals_host_bvh_on_triangle_soups(B, tmp_path):
         assert host.flat_bytes() == dev.flat_bytes(), name
         nodes, elems, depth = B.bvh_build(v, f)                              # the bare entry point
         assert len(nodes) == host.info.n_bvh_nodes and depth == host.info.max_bvh_depth and sorted(elems) == list(range(len(f)))
+        on, oe = O.bvh_build(v, f, 4)                                        # the checker: the oracle's cyBVH::Build
+        assert np.array_equal(nodes[1:], on[1:]) and np.array_equal(elems, oe), name
+        dm = dev.flat_view().mesh_arrays(0)
+        assert np.array_equal(dm["bvh_raw"][1:], on[1:]) and np.array_equal(dm["elems"], oe), name
         branches.add((len(f) <= 4, depth > 0))
     assert len(branches) >= 2
     with pytest.raises(B.BhrtError):

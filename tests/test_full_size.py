@@ -219,3 +219,29 @@ def test_every_sample_of_a_whole_caustic_frame_vs_oracle(gpu, load_scene, O):
     gs, st = sc.render_samples(opts, *region)
     assert np.nanmax(np.abs(gs - ro["samples"])) <= TOL
     assert st.photon_heavy_queries == stx.photon_heavy_queries and st.photon_exact_queries <= st.photon_heavy_queries // 20
+
+
+def test_config5_as_it_stands_one_million_photons_whole_frame_vs_oracle(gpu, O):
+    """BASELINE config 5 at its own size (what tools/soak_parity.py caustics runs by hand): 10^6 stored caustic photons — the same map byte
+    for byte as the oracle's BuildCausticPhotonMap (Main.cpp:342-386; ~6.4e7 emissions) — and every sample of the 1920x1080 frame at 2 spp,
+    GI depth 3, against the oracle's render with its own k-NN gather (cyPhotonMap.h:332-382,421-498): exact replay = identical bits, the
+    default selection pass within north_star's 1e-4 (measured 1.1e-5).  About a minute, most of it the oracle on the box's 16 cores."""
+    import os
+    sc = gpu.Scene(os.path.join(SCENES, "c5_caustics_hd.xml"))
+    n_photons = 1000000
+    sc.photon_build(gpu.default_opts(seed=0), n_photons)
+    bal, _, n_emit = O.photon_build(sc.flat_bytes(), n_photons, seed=0)
+    assert bal.shape[0] == n_photons and n_emit > 10 * n_photons
+    assert np.array_equal(sc.photon_get(), bal)
+    region = (0, 0, sc.width, sc.height)
+    assert (sc.width, sc.height) == (1920, 1080)
+    opts = gpu.default_opts(spp=2, gi_bounces=3, seed=1, photon_map=1)
+    opts.photon_exact = 1
+    gx, stx = sc.render_samples(opts, *region)
+    ro = O.render(sc.flat_bytes(), sc.width, sc.height, 2, gi=3, seed=1, region=region, photon=1, threads=16)["samples"]
+    assert same_bits(gx, ro)
+    assert stx.photon_heavy_queries > 50000 and stx.photon_exact_queries >= stx.photon_heavy_queries
+    opts.photon_exact = 0
+    gs, st = sc.render_samples(opts, *region)
+    assert np.nanmax(np.abs(gs - ro)) <= TOL
+    assert st.photon_heavy_queries == stx.photon_heavy_queries
