@@ -32,7 +32,7 @@ class Opts(C.Structure):
     _fields_ = [("spp", C.c_int32), ("gi_bounces", C.c_int32), ("internal_bounces", C.c_int32), ("seed", C.c_uint32),
                 ("jitter", C.c_int32), ("gamma", C.c_int32), ("photon_map", C.c_int32),
                 ("rank", C.c_int32), ("world_size", C.c_int32), ("tile_size", C.c_int32),
-                ("samples_per_pass", C.c_int32), ("timers", C.c_int32), ("photon_exact", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("samples_per_pass", C.c_int32), ("timers", C.c_int32), ("photon_exact", C.c_int32), ("leaf_skip", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Stats(C.Structure):

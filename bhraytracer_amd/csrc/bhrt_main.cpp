@@ -185,6 +185,8 @@ int main(int argc, char **argv)
         else if (s == "--seed") o.seed = (uint32_t)strtoul(next(), nullptr, 10);
         else if (s == "--no-jitter") o.jitter = 0;
         else if (s == "--no-gamma") o.gamma = 0;
+        else if (s == "--leaf-skip") o.leaf_skip = 1;
+        else if (s == "--photon-exact") o.photon_exact = 1;
         else if (s == "--device") A.device = atoi(next());
         else if (s == "--gpus") A.gpus = atoi(next());
         else if (s == "--rank") o.rank = atoi(next());

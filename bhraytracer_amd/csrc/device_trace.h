@@ -179,27 +179,42 @@ __device__ inline RayRcpF ray_rcp_f(V3 d)
 // 1 = hit, 0 = miss, -1 = too close to call.  One comparison decides both conditions: with u = min(tMax', t_max),
 // u - tMin' > tol means tMin < tMax and tMin < t_max for certain (tMax' >= u, and the error of tMax' relative to |u| is no
 // larger than relative to itself on the side that matters), u - tMin' < -tol means one of them fails for certain.
-__device__ inline int box_fast(const float *b, V3 o, const RayRcpF &r, float t_max, float &t_min_approx)
+__device__ inline int box_fast(const float *b, V3 o, const RayRcpF &r, float t_max, float &t_min_approx, float &t_max_approx /* of the slabs alone, without t_max */)
 {
     const float tz1 = (b[2] - o.z) * r.rz, tz2 = (b[5] - o.z) * r.rz;
     const float ty1 = (b[1] - o.y) * r.ry, ty2 = (b[4] - o.y) * r.ry;
     const float tx1 = (b[0] - o.x) * r.rx, tx2 = (b[3] - o.x) * r.rx;
     const float tMin = hw_max3(hw_min(tx1, tx2), hw_min(ty1, ty2), hw_min(tz1, tz2));
-    const float u = hw_min(hw_min3(hw_max(tx1, tx2), hw_max(ty1, ty2), hw_max(tz1, tz2)), t_max);
+    const float tMax = hw_min3(hw_max(tx1, tx2), hw_max(ty1, ty2), hw_max(tz1, tz2));
+    const float u = hw_min(tMax, t_max);
     const float diff = u - tMin, tol = fmaf(BHRT_FAST_REL, fabsf(tMin) + fabsf(u), BHRT_FAST_ABS);
     t_min_approx = tMin;
+    t_max_approx = tMax;
     return diff > tol ? 1 : (diff < -tol ? 0 : -1);
 }
+__device__ inline int box_fast(const float *b, V3 o, const RayRcpF &r, float t_max, float &t_min_approx)
+{
+    float t_max_approx;
+    return box_fast(b, o, r, t_max, t_min_approx, t_max_approx);
+}
 // the same for the any-hit loop, with fminf / fmaxf (see box_hit_rcp<false>: that loop schedules worse around the asm forms)
-__device__ inline int box_fast_f(const float *b, V3 o, const RayRcpF &r, float t_max)
+__device__ inline int box_fast_f(const float *b, V3 o, const RayRcpF &r, float t_max, float &t_min_approx, float &t_max_approx)
 {
     const float tz1 = (b[2] - o.z) * r.rz, tz2 = (b[5] - o.z) * r.rz;
     const float ty1 = (b[1] - o.y) * r.ry, ty2 = (b[4] - o.y) * r.ry;
     const float tx1 = (b[0] - o.x) * r.rx, tx2 = (b[3] - o.x) * r.rx;
     const float tMin = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
-    const float u = fminf(fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2)), t_max);
+    const float tMax = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+    const float u = fminf(tMax, t_max);
     const float diff = u - tMin, tol = fmaf(BHRT_FAST_REL, fabsf(tMin) + fabsf(u), BHRT_FAST_ABS);
+    t_min_approx = tMin;
+    t_max_approx = tMax;
     return diff > tol ? 1 : (diff < -tol ? 0 : -1);
+}
+__device__ inline int box_fast_f(const float *b, V3 o, const RayRcpF &r, float t_max)
+{
+    float a, c;
+    return box_fast_f(b, o, r, t_max, a, c);
 }
 // tmin1 < tmin2 from the approximations: 1 / 0, or -1 = too close to call
 __device__ inline int order_fast(float tmin1, float tmin2)
@@ -247,6 +262,9 @@ __device__ inline TriPlane tri_plane_ld(const bhrt_tri *tr)
     P.nx = a.x; P.ny = a.y; P.nz = a.z; P.nd = a.w; P.len = tr->vN_len;
     return P;
 }
+// kRange = false: without the range test `t > hInfo.z` (TriObj.cpp:92) — for a caller that tests the triangles of a leaf side by side and applies
+// that comparison itself, in triangle order, against the bound the earlier triangles have left
+template <bool kRange = true>
 __device__ inline bool tri_plane_test(const TriPlane &P, V3 o, V3 d, float dlen, int side, float t_cur, float &t, bool &hitFront)
 {
     // The reference returns at each failed test; here the cheap tests are evaluated straight through and AND-ed (a wave
@@ -268,7 +286,7 @@ __device__ inline bool tri_plane_test(const TriPlane &P, V3 o, V3 d, float dlen,
     }
     ok = ok && !grazing;
     t = (P.nd - dot(vN, o)) / t_divisor;
-    ok = ok && !(t <= 0 || t > t_cur);
+    ok = ok && !(t <= 0 || (kRange && t > t_cur));
     hitFront = t_divisor < 0;
     return ok && !(!hitFront && side == BHRT_HIT_FRONT) && !(hitFront && side == BHRT_HIT_BACK);
 }
@@ -330,6 +348,8 @@ struct MeshRef {
     const bhrt_bvh_node *lds;  // the first `n_lds` nodes (= the top levels) staged in LDS by the workgroup, or nullptr
     uint32_t n_lds;
     bool nested;               // bhrt_mesh::bvh_nested: a box-missed inner sibling cannot produce a hit (see skip_missed below)
+    const uint32_t *dpar;      // parent links of the breadth-first copy (in that copy a LEAF's `parent` word is its packed normal cone: leaf_skip)
+    float k0, k1, big, omax;   // bhrt_mesh::skip_*: the mesh-wide constants of leaf_skip (omax = 0: no leaf qualifies)
 };
 __device__ inline MeshRef mesh_ref(const DevScene &S, int mi)
 {
@@ -340,6 +360,8 @@ __device__ inline MeshRef mesh_ref(const DevScene &S, int mi)
     r.lds = nullptr;
     r.n_lds = 0;
     r.nested = m.bvh_nested != 0;
+    r.dpar = (const uint32_t *)(S.blob + m.off_dparent);
+    r.k0 = m.skip_k0; r.k1 = m.skip_k1; r.big = m.skip_big; r.omax = m.skip_omax;
     return r;
 }
 // TraceBVHNode visits the sibling of a child that returned nothing even when the sibling's box was missed (TriObj.cpp:245-248,
@@ -356,7 +378,35 @@ __device__ inline MeshRef mesh_ref(const DevScene &S, int mi)
 #ifndef BHRT_SKIP_MISSED
 #define BHRT_SKIP_MISSED 1
 #endif
-__device__ inline bool skip_missed(const MeshRef &M, bool box_hit, uint32_t data) { return BHRT_SKIP_MISSED && M.nested && !box_hit && !(data & 0x80000000u); }
+#ifndef BHRT_EXP_SKIP_LEAVES
+#define BHRT_EXP_SKIP_LEAVES 0 /* measurement only (unsound): box-missed LEAF siblings are left out as well */
+#endif
+__device__ inline bool skip_missed(const MeshRef &M, bool box_hit, uint32_t data) { return BHRT_SKIP_MISSED && M.nested && !box_hit && (BHRT_EXP_SKIP_LEAVES || !(data & 0x80000000u)); }
+// A box-missed LEAF sibling (36 % of the closed room's leaf visits, never a hit in 10^9 of them) is visited by the reference all the same, and its
+// triangles are tested without a box test: nothing in IntersectTriangle (TriObj.cpp:68-189) knows the box, and from far away the test's three
+// signed areas are rounding noise.  The visit may be left out when it PROVABLY accepts nothing (the proof, and what the host computes per
+// leaf and per mesh for it, is in scene_host.cpp::ComputeLeafSkip; DESIGN.md 4 "leaf skip").  The ray must
+//   * be tame: max |o_i| <= M.omax (and no zero / tiny / huge direction component: the approximate slab test was decisive);
+//   * MISS the leaf box inflated by m = k0 + k1 max|o_i| as a LINE (not merely lie beyond the current hit): with tMin / tMax the approximate
+//     slab values of the plain box, inflating by m moves every quotient by at most m max|1/d_i|, so  tMin - tMax > 2 m max|1/d_i| + tol  does it;
+//   * pass through the box inflated by `big` (a NEAR miss: the hit point with a triangle's plane then stays close enough for the sign test to
+//     be exact):  tMin - tMax < 2 big min|1/d_i| - tol;
+//   * not graze any triangle of the leaf: |d . A| >= |d| with A the leaf's packed cone (three 10-bit components, 2-bit exponent; 0 = never).
+// aux = the leaf's `parent` word in the breadth-first copy.  tol: twice the slab test's own (the bounds here are about real arithmetic).
+// Compiled into the walks of a render with bhrt_opts::leaf_skip only (template parameter kLS of walk_round / mesh_shadow_stack and the kernels that
+// hold them): its mere presence in the default kernels — behind a wave-uniform branch never taken — cost them 3-11 % (registers, code layout).
+__device__ inline bool leaf_skip(const MeshRef &M, uint32_t aux, float tmin, float tmax, V3 o, V3 d, const RayRcpF &rf, float dlen)
+{
+    if (aux == 0u) return false;
+    const float omax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+    const float rmax = fmaxf(fmaxf(fabsf(rf.rx), fabsf(rf.ry)), fabsf(rf.rz)), rmin = fminf(fminf(fabsf(rf.rx), fabsf(rf.ry)), fabsf(rf.rz));
+    const float gap = tmin - tmax, tol = fmaf(2.f * BHRT_FAST_REL, fabsf(tmin) + fabsf(tmax), BHRT_FAST_ABS);
+    const float m = fmaf(M.k1, omax, M.k0);
+    bool ok = omax <= M.omax && gap > fmaf(2.000002f * m, rmax, tol) && gap < fmaf(1.999998f * M.big, rmin, -tol);
+    const int qx = (int)(aux << 22) >> 22, qy = (int)(aux << 12) >> 22, qz = (int)(aux << 2) >> 22, e = (int)(aux >> 30);
+    const float dq = d.x * (float)qx + d.y * (float)qy + d.z * (float)qz;
+    return ok && fabsf(dq) >= ldexpf(dlen, 8 - e) * 1.000244140625f; // (1 + 2^-12): the rounding of the three products and of |d|
+}
 // one BVH node (32 B) from the LDS nodelet when it is one of the staged top levels, else from global memory
 struct NodeRec {
     float b[6];
@@ -395,7 +445,7 @@ __device__ inline void node_pair_at(const MeshRef &M, uint32_t c1, NodeRec &n1, 
     n2.b[0] = c.x; n2.b[1] = c.y; n2.b[2] = c.z; n2.b[3] = c.w; n2.b[4] = d.x; n2.b[5] = d.y;
     n2.data = __float_as_uint(d.z); n2.parent = __float_as_uint(d.w);
 }
-__device__ inline uint32_t node_parent(const MeshRef &M, uint32_t i) { return i < M.n_lds ? M.lds[i].parent : M.bvh[i].parent; }
+__device__ inline uint32_t node_parent(const MeshRef &M, uint32_t i) { return M.dpar[i]; }
 __device__ inline uint32_t node_data(const MeshRef &M, uint32_t i) { return i < M.n_lds ? M.lds[i].data : M.bvh[i].data; }
 
 // the same from global memory only (mesh_closest_vote: with a nodelet the pointer select turns every node fetch into a flat
@@ -639,7 +689,7 @@ __device__ inline void walk_begin(const MeshRef &M, MeshWalk &W, V3 o, V3 d, flo
     W.r = false; W.any = false;
 }
 // One round: the wave runs the phase most of its lanes wait for (nD / nL / nC = lanes waiting for a descend step / a leaf / a climb step).
-template <class PathT> // uint16_t (pair indices < 2^16: meshes below 2^17 nodes) or uint32_t
+template <class PathT, bool kLS = false> // PathT: uint16_t (pair indices < 2^16: meshes below 2^17 nodes) or uint32_t; kLS: bhrt_opts::leaf_skip
 __device__ inline void walk_round(const MeshRef &M, MeshWalk &W, int side, float &ht, int &hprim, int &hfront, PathT *stack, uint32_t stride, int nD, int nL, int nC)
 {
     const V3 o = W.o, d = W.d;
@@ -656,7 +706,9 @@ __device__ inline void walk_round(const MeshRef &M, MeshWalk &W, int side, float
             NodeRec n1, n2;
             node_pair_at_g(M, c1, n1, n2);
             const uint32_t d1 = n1.data, d2 = n2.data;
-            const int f1 = W.rf.slow ? -1 : box_fast(n1.b, o, W.rf, ht, tmin1), f2 = W.rf.slow ? -1 : box_fast(n2.b, o, W.rf, ht, tmin2);
+            float tmx1 = 0.f, tmx2 = 0.f;
+            const int f1 = W.rf.slow ? -1 : box_fast(n1.b, o, W.rf, ht, tmin1, tmx1), f2 = W.rf.slow ? -1 : box_fast(n2.b, o, W.rf, ht, tmin2, tmx2);
+            const float at1 = tmin1, at2 = tmin2; // the approximate slab values (leaf_skip)
             bool b1 = f1 == 1, b2 = f2 == 1;
             int ord = (b1 && b2) ? order_fast(tmin1, tmin2) : (b1 ? 1 : 0);
             WALK_DBG(0, 1); WALK_DBG(1, __popcll(__ballot(true)));
@@ -679,7 +731,13 @@ __device__ inline void walk_round(const MeshRef &M, MeshWalk &W, int side, float
                 W.depth++;
                 const uint32_t bit = 1u << (W.depth - 1);
                 const bool first1 = ord == 1;
-                W.inFar = skip_missed(M, first1 ? b2 : b1, first1 ? d2 : d1) ? (W.inFar | bit) : (W.inFar & ~bit);
+                bool sib_done = skip_missed(M, first1 ? b2 : b1, first1 ? d2 : d1);
+                // a box-missed LEAF sibling whose visit provably accepts nothing (the approximate test itself must have said "missed")
+                if (kLS && M.omax > 0.f && !sib_done && ((first1 ? d2 : d1) & 0x80000000u) && (first1 ? f2 : f1) == 0 && !(first1 ? b2 : b1)) {
+                    sib_done = leaf_skip(M, first1 ? n2.parent : n1.parent, first1 ? at2 : at1, first1 ? tmx2 : tmx1, o, d, W.rf, W.dlen);
+                    WALK_DBG(14, 1); WALK_DBG(15, sib_done ? 1 : 0);
+                }
+                W.inFar = sib_done ? (W.inFar | bit) : (W.inFar & ~bit);
                 W.nearHit &= ~bit;
                 W.data = first1 ? d1 : d2;
                 W.sides = first1 ? (W.sides & ~bit) : (W.sides | bit);
@@ -736,7 +794,7 @@ __device__ inline void walk_round(const MeshRef &M, MeshWalk &W, int side, float
         }
     }
 }
-template <class PathT>
+template <class PathT, bool kLS = false>
 __device__ inline bool mesh_closest_vote(const MeshRef &M, V3 o, V3 d, int side, float &ht, int &hprim, int &hfront, PathT *stack, uint32_t stride)
 {
     MeshWalk W;
@@ -744,7 +802,7 @@ __device__ inline bool mesh_closest_vote(const MeshRef &M, V3 o, V3 d, int side,
     while (true) {
         const int nD = __popcll(__ballot(W.st == 0)), nL = __popcll(__ballot(W.st == 1)), nC = __popcll(__ballot(W.st == 2));
         if (nD + nL + nC == 0) break;
-        walk_round(M, W, side, ht, hprim, hfront, stack, stride, nD, nL, nC);
+        walk_round<PathT, kLS>(M, W, side, ht, hprim, hfront, stack, stride, nD, nL, nC);
     }
     return W.any;
 }
@@ -795,7 +853,7 @@ __device__ inline bool mesh_shadow(const MeshRef &M, V3 o, V3 d, float t_max)
 
 // mesh_shadow with the path in LDS (see mesh_closest_vote): after a subtree the walk continues at the second child of the
 // deepest level still in its first child, found by a bit scan; no parent links are read.
-template <class PathT>
+template <class PathT, bool kLS = false>
 __device__ inline bool mesh_shadow_stack(const MeshRef &M, V3 o, V3 d, float t_max, PathT *stack, uint32_t stride)
 {
     float tm;
@@ -817,7 +875,9 @@ __device__ inline bool mesh_shadow_stack(const MeshRef &M, V3 o, V3 d, float t_m
                 const uint32_t c1 = data & 0x7fffffffu;
                 float t1, t2;
                 const NodeRec n1 = node_at(M, c1), n2 = node_at(M, c1 + 1);
-                int f1 = rf.slow ? -1 : box_fast_f(n1.b, o, rf, BHRT_BIGFLOAT), f2 = rf.slow ? -1 : box_fast_f(n2.b, o, rf, BHRT_BIGFLOAT);
+                float a1 = 0.f, x1 = 0.f, a2 = 0.f, x2 = 0.f;
+                int f1 = rf.slow ? -1 : box_fast_f(n1.b, o, rf, BHRT_BIGFLOAT, a1, x1), f2 = rf.slow ? -1 : box_fast_f(n2.b, o, rf, BHRT_BIGFLOAT, a2, x2);
+                const bool m1 = f1 == 0, m2 = f2 == 0; // missed, by the approximate test's own verdict (leaf_skip)
                 if (f1 < 0 || f2 < 0) { // the exact form: its double reciprocals only here (kept across the loop they cost twelve registers)
                     const RayRcp rr = ray_rcp(d);
                     if (f1 < 0) f1 = box_hit_rcp<false>(n1.b, o, d, rr, BHRT_BIGFLOAT, t1) ? 1 : 0;
@@ -826,11 +886,13 @@ __device__ inline bool mesh_shadow_stack(const MeshRef &M, V3 o, V3 d, float t_m
                 if (f1 != 1 && f2 != 1) st = 2;
                 else {
                     // TraceBVHShadow visits both children once either box is hit; a box-missed inner child ends at its own two box
-                    // tests (skip_missed): child 1 is stepped over, child 2 marked done
+                    // tests (skip_missed): child 1 is stepped over, child 2 marked done.  A box-missed LEAF child likewise when its visit
+                    // provably accepts nothing (leaf_skip).
                     depth++;
                     const uint32_t bit = 1u << (depth - 1);
-                    const bool over1 = skip_missed(M, f1 == 1, n1.data);
-                    inSecond = (over1 || skip_missed(M, f2 == 1, n2.data)) ? (inSecond | bit) : (inSecond & ~bit);
+                    const bool over1 = skip_missed(M, f1 == 1, n1.data) || (kLS && M.omax > 0.f && m1 && (n1.data & 0x80000000u) && leaf_skip(M, n1.parent, a1, x1, o, d, rf, dlen));
+                    const bool over2 = skip_missed(M, f2 == 1, n2.data) || (kLS && M.omax > 0.f && m2 && (n2.data & 0x80000000u) && leaf_skip(M, n2.parent, a2, x2, o, d, rf, dlen));
+                    inSecond = (over1 || over2) ? (inSecond | bit) : (inSecond & ~bit);
                     stack[(uint32_t)depth * stride] = (PathT)(c1 >> 1);
                     data = over1 ? n2.data : n1.data;
                     st = (data & 0x80000000u) ? 1 : 0;
@@ -946,7 +1008,7 @@ __device__ inline uint32_t park_spread(uint32_t v) // low bits -> every third bi
 // crosses — the reference walks (nearly) the whole tree for it, and so does the traversal here: ~10^5 sequential rounds for the
 // 100 k-triangle mesh.  The samplers produce such rays at a rate of ~1.5e-8 per diffuse GI ray off an axis-aligned wall (a 31-bit draw
 // below 2^-25 makes theta exactly 0 in GetSampleInSemiSphere, MtlBlinn.cpp:697-716: the ray leaves along the normal).
-template <bool kMeshes = true, class PathT = uint16_t>
+template <bool kMeshes = true, class PathT = uint16_t, bool kLS = false>
 __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit &h, bool active = true, bhrt_bvh_node *lds = nullptr, int start = 0,
                                     bool park = false, uint32_t *park_key = nullptr, PathT *path = nullptr, uint32_t path_stride = 0,
                                     uint32_t lds_nodes = BHRT_LDS_NODES, bool camera = false /* o = the camera position */, bool *park_slow = nullptr)
@@ -990,7 +1052,7 @@ __device__ inline int trace_closest(const DevScene &S, V3 o, V3 d, int side, Hit
                 }
             }
         } else {
-            if (path ? mesh_closest_vote(M, lp, ld, side, h.t, h.prim, h.front, path, path_stride) : mesh_closest(M, lp, ld, side, h.t, h.prim, h.front)) h.node = n;
+            if (path ? mesh_closest_vote<PathT, kLS>(M, lp, ld, side, h.t, h.prim, h.front, path, path_stride) : mesh_closest(M, lp, ld, side, h.t, h.prim, h.front)) h.node = n;
         }
     }
     return parked;
@@ -1019,7 +1081,7 @@ __device__ inline void trace_closest_coop(const DevScene &S, CoopLds &L, V3 o, V
 // other, so nodes are tested in index order; each test is the reference's (including its quirks Q1-Q3).
 // kMode 3: the scene has no mesh (BVH code not compiled in).  kMode 0: everything.  kMode 1: spheres and planes only; returns 2.f instead of 1.f when the ray also hits the root
 // box of a mesh (the caller parks it for k_shadow_mesh).  kMode 2: the meshes only.
-template <int kMode, class PathT = uint16_t>
+template <int kMode, class PathT = uint16_t, bool kLS = false>
 __device__ inline float trace_shadow_t(const DevScene &S, V3 o, V3 d, float t_max, PathT *path = nullptr, uint32_t path_stride = 0)
 {
     V3 rp = o, rd = d;
@@ -1060,7 +1122,7 @@ __device__ inline float trace_shadow_t(const DevScene &S, V3 o, V3 d, float t_ma
             float tm; // the root box gate of TriObj::ShadowRecursive (TriObj.cpp:41-54), repeated by mesh_shadow
             if (!wants_mesh && box_hit_lazy<false>(node_at(mesh_ref(S, S.nodes[n].mesh), 1).b, lp, ld, ray_rcp_f(ld), BHRT_BIGFLOAT, tm)) wants_mesh = true;
         } else {
-            if (path ? mesh_shadow_stack(mesh_ref(S, S.nodes[n].mesh), lp, ld, t_max, path, path_stride) : mesh_shadow(mesh_ref(S, S.nodes[n].mesh), lp, ld, t_max)) return 0.f;
+            if (path ? mesh_shadow_stack<PathT, kLS>(mesh_ref(S, S.nodes[n].mesh), lp, ld, t_max, path, path_stride) : mesh_shadow(mesh_ref(S, S.nodes[n].mesh), lp, ld, t_max)) return 0.f;
         }
     }
     return wants_mesh ? 2.f : 1.f;

@@ -364,7 +364,7 @@ constexpr uint32_t kMeshNodelet = 256;
 #define BHRT_MESH_BLOCK 64 /* threads per workgroup of the key-sorted (non-camera) launches: a wave leaves as soon as its own rays are done (256: +3 % on the closed room) */
 #endif
 constexpr int kMeshBlock = BHRT_MESH_BLOCK;
-template <bool kCamera, int kPath> // kPath: 0 parent links, 1 path in LDS with 16-bit entries, 2 with 32-bit entries
+template <bool kCamera, int kPath, bool kLS = false> // kPath: 0 parent links, 1 path in LDS with 16-bit entries, 2 with 32-bit entries; kLS: bhrt_opts::leaf_skip
 __global__ void __launch_bounds__(kCamera ? kBlock : kMeshBlock, 6) k_trace_mesh(DevScene S, PassInfo P, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
 {
     typedef typename std::conditional<kPath == 2, uint32_t, uint16_t>::type PathT;
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(kCamera ? kBlock : kMeshBlock, 6) k_trace_mesh
         hit.front = fw & 0xff;
         start = (fw >> 8) - 1;
     }
-    trace_closest<true, PathT>(S, o, d, (int)((meta >> 4) & 3u), hit, active, kPath ? nullptr : nodelet, active ? start : S.n_nodes, false, nullptr,
+    trace_closest<true, PathT, kLS>(S, o, d, (int)((meta >> 4) & 3u), hit, active, kPath ? nullptr : nodelet, active ? start : S.n_nodes, false, nullptr,
                                kPath ? path + threadIdx.x : (PathT *)nullptr, kTB, kMeshNodelet);
     if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; }
     // key-sorted rays are filed for shading by k_file_parked, in queue order instead of traversal order
@@ -425,7 +425,7 @@ __device__ unsigned long long g_stream_t[4]; // wall clock (100 MHz): first wave
 #ifdef BHRT_DEBUG_STREAM
 __device__ unsigned long long g_stream_dbg[8]; // rounds, lanes with a walk, lanes in the round's phase, clocks in rounds, clocks outside, refills, descend / leaf rounds
 #endif
-template <int kPath> // 1: 16-bit path entries, 2: 32-bit (see k_trace_mesh)
+template <int kPath, bool kLS = false> // 1: 16-bit path entries, 2: 32-bit (see k_trace_mesh)
 __global__ void __launch_bounds__(64, BHRT_STREAM_OCC) k_trace_mesh_stream(DevScene S, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
 {
     typedef typename std::conditional<kPath == 2, uint32_t, uint16_t>::type PathT;
@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(64, BHRT_STREAM_OCC) k_trace_mesh_stream(DevSc
 #ifdef BHRT_DEBUG_STREAM
             const unsigned long long r0 = __builtin_readcyclecounter();
 #endif
-            walk_round(M, W, side, hit.t, hit.prim, hit.front, stack, 64u, nD, nL, nC);
+            walk_round<PathT, kLS>(M, W, side, hit.t, hit.prim, hit.front, stack, 64u, nD, nL, nC);
 #ifdef BHRT_DEBUG_STREAM
             if (nD >= nL && nD > 0) dbg[4] += __builtin_readcyclecounter() - r0; // descend rounds
 #endif
@@ -634,7 +634,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_shadow_park(DevScene S, Shadow
 #define BHRT_SHADOW_BLOCK 64 /* threads per workgroup of k_shadow_mesh (a divisor of kBlock): a wave leaves as soon as its own rays are done (256: any-hit group +6-7 % on C3 and the closed room) */
 #endif
 constexpr int kShadowBlock = BHRT_SHADOW_BLOCK;
-template <int kPath> // kPath: traversal path in LDS (mesh_shadow_stack), same modes as k_trace_mesh
+template <int kPath, bool kLS = false> // kPath: traversal path in LDS (mesh_shadow_stack), same modes as k_trace_mesh
 __global__ void __launch_bounds__(kShadowBlock) k_shadow_mesh(DevScene S, ShadowQueue q, float *vis, RayOrder ord)
 {
     typedef typename std::conditional<kPath == 2, uint32_t, uint16_t>::type PathT;
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(kShadowBlock) k_shadow_mesh(DevScene S, Shadow
     if (!xcd_slice(blockIdx.x / kParts, ord.mesh_start[BHRT_ORDER_SHARDS], slice)) return;
     if (!parked_entry(ord, slice, &s_seg, i, (blockIdx.x % kParts) * kShadowBlock)) return;
     if (i == 0xffffffffu) return;
-    vis[q.frame[i]] = trace_shadow_t<2, PathT>(S, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), q.tmax[i], kPath ? path + threadIdx.x : (PathT *)nullptr, kShadowBlock);
+    vis[q.frame[i]] = trace_shadow_t<2, PathT, kLS>(S, v3(q.ox[i], q.oy[i], q.oz[i]), v3(q.dx[i], q.dy[i], q.dz[i]), q.tmax[i], kPath ? path + threadIdx.x : (PathT *)nullptr, kShadowBlock);
 }
 
 // segment table of the parked mesh rays for k_trace_mesh: 32 shards, one lane each
@@ -2048,6 +2048,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
     if (pass_samples < (uint32_t)o.spp) pass_samples = (uint32_t)o.spp;
     D->timers = o.timers;
     D->photon_exact = o.photon_exact;
+    const bool ls = o.leaf_skip != 0; // the walks' instantiations with device_trace.h::leaf_skip compiled in
     int path_mode = 1; // the traversal's path in LDS: 1 = 16-bit pair indices, 2 = 32-bit (a mesh with 2^17 nodes or more), 0 = no (deeper than 32 levels)
     {
         const bhrt_mesh *hm = (const bhrt_mesh *)(scene->flat.blob.data() + H->off_meshes);
@@ -2160,14 +2161,14 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                         hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, RO.park_bucket, n_buckets, RO.park_bucket + n_buckets);
                         hipLaunchKernelGGL(k_park_scatter, pg, tb, 0, D->stream, RO);
                     }
-                    auto mesh_kernel = first_step ? (path_mode == 1 ? k_trace_mesh<true, 1> : path_mode == 2 ? k_trace_mesh<true, 2> : k_trace_mesh<true, 0>)
+                    auto mesh_kernel = first_step ? (path_mode == 1 ? (ls ? k_trace_mesh<true, 1, true> : k_trace_mesh<true, 1>) : path_mode == 2 ? (ls ? k_trace_mesh<true, 2, true> : k_trace_mesh<true, 2>) : k_trace_mesh<true, 0>)
                                                   : (path_mode == 1 ? k_trace_mesh<false, 1> : path_mode == 2 ? k_trace_mesh<false, 2> : k_trace_mesh<false, 0>);
                     if (!first_step && path_mode != 0 && stream_waves > 0)
                     {
 #ifdef BHRT_DEBUG_DRAIN
                         { unsigned long long t0[4] = {~0ull, ~0ull, 0, 0}; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stream_t), t0, sizeof(t0))); }
 #endif
-                        hipLaunchKernelGGL(path_mode == 1 ? k_trace_mesh_stream<1> : k_trace_mesh_stream<2>, dim3(std::min<uint32_t>((n_cur + 63) / 64, stream_waves)), dim3(64), 0, D->stream, D->S,
+                        hipLaunchKernelGGL(path_mode == 1 ? (ls ? k_trace_mesh_stream<1, true> : k_trace_mesh_stream<1>) : (ls ? k_trace_mesh_stream<2, true> : k_trace_mesh_stream<2>), dim3(std::min<uint32_t>((n_cur + 63) / 64, stream_waves)), dim3(64), 0, D->stream, D->S,
                                            Q[cur], HB, RO, D->d_cnt);
 #ifdef BHRT_DEBUG_DRAIN
                         unsigned long long t1[4];
@@ -2208,7 +2209,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                     hipLaunchKernelGGL(k_trace_shadow_park, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis, RO, D->d_cnt);
                     hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream, D->d_cnt, RO);
                     // (streamed like k_trace_mesh_stream the any-hit walks gain nothing: they are short, C4 +4 ms, closed room -2 ms)
-                    hipLaunchKernelGGL(path_mode == 1 ? k_shadow_mesh<1> : path_mode == 2 ? k_shadow_mesh<2> : k_shadow_mesh<0>, dim3((hg.x + BHRT_ORDER_SHARDS) * (kBlock / kShadowBlock)), dim3(kShadowBlock), 0, D->stream, D->S, SQ, F.vis, RO);
+                    hipLaunchKernelGGL(path_mode == 1 ? (ls ? k_shadow_mesh<1, true> : k_shadow_mesh<1>) : path_mode == 2 ? (ls ? k_shadow_mesh<2, true> : k_shadow_mesh<2>) : k_shadow_mesh<0>, dim3((hg.x + BHRT_ORDER_SHARDS) * (kBlock / kShadowBlock)), dim3(kShadowBlock), 0, D->stream, D->S, SQ, F.vis, RO);
                 } else hipLaunchKernelGGL(k_trace_shadow<false>, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis);
                 t.Stop();
             }
@@ -2254,7 +2255,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             unsigned long long w[16], wz[16] = {};
             HIP_CHECK(hipMemcpyFromSymbol(w, HIP_SYMBOL(g_walk_dbg), sizeof(w)));
             HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_walk_dbg), wz, sizeof(wz)));
-            fprintf(stderr, "walk: descend bodies %llu (%.1f lanes), exact boxes %llu (%.1f lanes), climbs %llu (%.1f lanes), climbs after a hit %llu (%.1f lanes), triangle slots %llu (%.1f lanes), barycentric parts %llu (%.1f lanes), exact grazing quotients %llu; exact boxes by cause: slow %llu, hit test %llu, order %llu\n",
+            fprintf(stderr, "walk: descend bodies %llu (%.1f lanes), exact boxes %llu (%.1f lanes), climbs %llu (%.1f lanes), climbs after a hit %llu (%.1f lanes), triangle slots %llu (%.1f lanes), barycentric parts %llu (%.1f lanes), exact grazing quotients %llu; exact boxes %llu; box-missed leaf siblings %llu, of them left out %llu\n",
                     w[0], w[0] ? (double)w[1] / w[0] : 0., w[2], w[2] ? (double)w[3] / w[2] : 0., w[4], w[4] ? (double)w[5] / w[4] : 0., w[6], w[6] ? (double)w[7] / w[6] : 0., w[8],
                     w[8] ? (double)w[9] / w[8] : 0., w[10], w[10] ? (double)w[11] / w[10] : 0., w[12], w[13], w[14], w[15]);
             fprintf(stderr, "stream: %llu rounds (%llu descend, %llu leaf), walking %.3f, in phase %.3f, clocks in rounds %.3g of which descend rounds %.3g, %llu refills\n", d[0], d[6],

@@ -14,6 +14,7 @@
 
 #include <ctype.h>
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -470,6 +471,150 @@ struct Loader {
 // ------------------------------------------------------------------------------------------------
 // blob writer
 // ------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Leaf skip (DESIGN.md 4 "leaf skip"; the device side is device_trace.h::leaf_skip).  TraceBVHNode visits the sibling of a child that
+// returned nothing even when the sibling's box was missed (TriObj.cpp:245-248,263-266), and TraceBVHShadow visits both children once
+// either box is hit (TriObj.cpp:286-300).  When that box-missed node is a LEAF the visit runs IntersectTriangle (TriObj.cpp:68-189) on its
+// triangles with no box test — and nothing ties that function's arithmetic to the slab test's: from far away its three signed areas are
+// rounding noise and a triangle can be "hit" by a ray that passes it at a distance.  So a leaf may only be left out when a proof says
+// that none of its triangles can be accepted for THIS ray.  What is computed here, per leaf, in double precision with every bound doubled:
+//
+// Notation: u = 2^-24; T a triangle of the leaf with the float normal n = vN, c = vN.v0 (float), projected on the plane that drops the axis
+// of the largest |n_i| (slope = (|n_a| + |n_b|) / |n_axis| <= 2); Q = the 2-D point the test projects its hit point X = fl(o + fl(t d)) to.
+//  (1) 2-D sign test (tri_areas).  Every computed area is the exact cross product of the two vertex differences as seen from Q, up to
+//      |err| <= 4.1 u |p_i - Q| |p_j - Q| (two rounded differences, two products, one sum; halving is exact).  For Q outside T at distance y
+//      (nearest point on an edge, or a vertex with interior angle alpha) one of the exact areas is negative with magnitude >= e s y
+//      (e = shortest edge, s = sin(alpha_min / 2)) and, the three summing to the triangle's own |c_T|, one is >= |c_T| / 3; both are computed
+//      with their true signs — mixed signs, i.e. REJECT — while  e s y > 4.1 u (y + E)^2  and  |c_T| / 3 > 4.1 u (y + E)^2  (E = longest
+//      edge): for  delta_T < y < L_T  with delta_T, L_T the roots / bounds of those two inequalities.
+//  (2) How far X can be.  X lies within rho of the ray's line and within a rounding error of T's plane; if the line passes through the leaf
+//      box inflated by `big` (point P) and |cos(n, d)| >= kappa0 = 1/16 for every triangle of the leaf, then |X - v0| <= (1 + 1.001 / kappa0)
+//      diag(box + 2 big) + 1e-3 (for |o|, |box| <= 1024).  The leaf qualifies when that is below every L_T: the "far" branch of (1) cannot occur.
+//  (3) Hence an accepted X has Q within delta_T of T's projection, its third coordinate within slope delta_T + G_T + 64 u (omax + B + 1) of
+//      T's extent (G_T = how far T's own vertices are off the float plane), so X lies in T's box inflated by that, and the ray's line
+//      passes through the LEAF box inflated by m = k0 + k1 omax  (k1 = 128 u;  k0 >= 2 max_T max(delta_T, slope delta_T + G_T) + 128 u (B + 1)).
+//      A ray whose line MISSES the leaf box inflated by m cannot be accepted by any triangle of the leaf.
+//  The angle condition of (2) is a cone: all unit normals of the leaf within omega of an axis a; a ray with |d.a| >= mu |d|,
+//  mu = cos(acos(kappa0) - omega - margin), keeps |cos(n, d)| >= kappa0.  The cone is stored in the leaf's `parent` word of the breadth-first
+//  copy as three 10-bit components of A = a / mu and a 2-bit exponent, rounded towards zero and VERIFIED after dequantising.
+static uint32_t PackCone(const double A[3], double Aq[3])
+{
+    double mx = std::max(fabs(A[0]), std::max(fabs(A[1]), fabs(A[2])));
+    if (!(mx > 0) || !(mx < 16.0)) return 0;
+    int e = 0;
+    while (e < 3 && mx >= ldexp(511.0, e - 8)) e++;
+    if (mx >= ldexp(511.0, e - 8)) return 0;
+    uint32_t w = (uint32_t)e << 30;
+    for (int k = 0; k < 3; k++) {
+        const int q = (int)trunc(ldexp(A[k], 8 - e)); // towards zero: |Aq| <= |A|
+        Aq[k] = ldexp((double)q, e - 8);
+        w |= ((uint32_t)q & 0x3ffu) << (10 * k);
+    }
+    return w;
+}
+static void ComputeLeafSkip(const HostMesh &m, const std::vector<bhrt_tri> &lt, std::vector<bhrt_bvh_node> &dn, std::vector<uint32_t> &dparent, bhrt_mesh &o)
+{
+    const double u = ldexp(1.0, -24), kappa0 = 1.0 / 16.0, c4 = 4.1 * u, tiny = ldexp(1.0, -100);
+    dparent.assign(dn.size(), 0);
+    for (size_t i = 0; i < dn.size(); i++) dparent[i] = dn[i].parent;
+    o.skip_k0 = o.skip_k1 = o.skip_big = o.skip_omax = 0;
+    for (size_t i = 1; i < dn.size(); i++)
+        if (dn[i].data & 0x80000000u) dn[i].parent = 0; // a leaf's word holds its cone from here on: 0 = never skipped
+    double B = 0;
+    for (int k = 0; k < 3; k++) B = std::max(B, std::max(fabs((double)m.bound_min[k]), fabs((double)m.bound_max[k])));
+    if (!(B <= 1024.0) || dn.size() < 2) return;
+    double diag_sum = 0;
+    size_t n_leaves = 0;
+    for (size_t i = 1; i < dn.size(); i++)
+        if (dn[i].data & 0x80000000u) {
+            double s2 = 0;
+            for (int k = 0; k < 3; k++) { const double ex = (double)dn[i].b[k + 3] - (double)dn[i].b[k]; s2 += ex * ex; }
+            diag_sum += sqrt(s2);
+            n_leaves++;
+        }
+    if (!n_leaves || !(diag_sum > 0)) return;
+    const double big = (getenv("BHRT_DBG_BIG") ? atof(getenv("BHRT_DBG_BIG")) : 2.0) * diag_sum / (double)n_leaves;
+    size_t why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double k1 = 128.0 * u, k0 = ldexp(B + 1.0, -13);
+    size_t n_ok = 0;
+    for (size_t i = 1; i < dn.size(); i++) {
+        if (!(dn[i].data & 0x80000000u)) continue;
+        const uint32_t cnt = ((dn[i].data >> 28) & 7u) + 1, off = dn[i].data & 0x0fffffffu;
+        bool ok = true;
+        double m0 = 0, Lmin = 1e300, axis_sum[3] = {0, 0, 0};
+        double nrm[8][3];
+        for (uint32_t t = 0; t < cnt && ok; t++) {
+            const bhrt_tri &tr = lt[off + t];
+            const uint32_t axis = tr.face_axis >> 30, face = tr.face_axis & 0x3fffffffu;
+            const double n[3] = {tr.vN[0], tr.vN[1], tr.vN[2]}, c = tr.vN_dot_v0;
+            const double nl = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            if (axis > 2 || !(nl > 0) || !std::isfinite(nl)) { ok = false; break; }
+            for (int k = 0; k < 3; k++) { nrm[t][k] = n[k] / nl; axis_sum[k] += nrm[t][k]; }
+            const double p[3][2] = {{tr.p0[0], tr.p0[1]}, {tr.p1[0], tr.p1[1]}, {tr.p2[0], tr.p2[1]}};
+            double len[3], E = 0, e = 1e300;
+            for (int k = 0; k < 3; k++) { // edge k = (p_{k+1}, p_{k+2})
+                const double dx = p[(k + 2) % 3][0] - p[(k + 1) % 3][0], dy = p[(k + 2) % 3][1] - p[(k + 1) % 3][1];
+                len[k] = sqrt(dx * dx + dy * dy);
+                E = std::max(E, len[k]); e = std::min(e, len[k]);
+            }
+            const double cT = fabs((p[1][0] - p[0][0]) * (p[2][1] - p[0][1]) - (p[1][1] - p[0][1]) * (p[2][0] - p[0][0])) * (1.0 - 1e-9);
+            if (!(cT > 0) || !(e > 0)) { ok = false; break; }
+            double s = 1.0; // sin(alpha_min / 2); the angle at vertex k lies between edges k+1 and k+2 and has sin(alpha_k) = cT / (their lengths)
+            for (int k = 0; k < 3; k++) {
+                const double la = len[(k + 1) % 3], lb = len[(k + 2) % 3];
+                const double ax = p[(k + 1) % 3][0] - p[k][0], ay = p[(k + 1) % 3][1] - p[k][1], bx = p[(k + 2) % 3][0] - p[k][0], by = p[(k + 2) % 3][1] - p[k][1];
+                const double cosa = std::max(-1.0, std::min(1.0, (ax * bx + ay * by) / (lb * la) * (1.0 + 1e-9) + 1e-12)); // edges at vertex k have lengths len[k+2] and len[k+1]
+                s = std::min(s, sqrt(std::max(0.0, (1.0 - cosa) / 2.0)));
+            }
+            s *= (1.0 - 1e-6);
+            // e s y > c4 (y + E)^2 + tiny  <=>  c4 y^2 - (e s - 2 c4 E) y + c4 E^2 + tiny < 0
+            const double bq = e * s - 2.0 * c4 * E, disc = bq * bq - 4.0 * c4 * (c4 * E * E + tiny);
+            if (!(bq > 0) || !(disc > 0)) { ok = false; break; }
+            const double y_lo = (bq - sqrt(disc)) / (2.0 * c4), y_hi = (bq + sqrt(disc)) / (2.0 * c4);
+            const double L1 = sqrt(cT / (3.0 * c4)) - E;
+            const double delta = 2.0 * y_lo + tiny, L = 0.5 * std::min(L1, y_hi);
+            if (!(delta < L)) { ok = false; break; }
+            Lmin = std::min(Lmin, L);
+            const int ia = axis == 0 ? 1 : 0, ib = axis == 2 ? 1 : 2;
+            const double slope = (fabs(n[ia]) + fabs(n[ib])) / fabs(n[axis]);
+            double G = 0;
+            for (int k = 0; k < 3; k++) {
+                const float *pv = &m.v[(size_t)m.f[(size_t)face * 3 + k] * 3];
+                G = std::max(G, fabs(n[0] * pv[0] + n[1] * pv[1] + n[2] * pv[2] - c) / fabs(n[axis]));
+            }
+            m0 = std::max(m0, std::max(delta, slope * delta + G));
+        }
+        if (!ok) { why[0]++; continue; }
+        if (!(2.0 * m0 + 128.0 * u * (B + 1.0) <= k0)) { why[1]++; continue; }
+        double d2 = 0;
+        for (int k = 0; k < 3; k++) { const double ex = (double)dn[i].b[k + 3] - (double)dn[i].b[k] + 2.0 * big; d2 += ex * ex; }
+        if (!((1.0 + 1.001 / kappa0) * sqrt(d2) + 1e-3 <= Lmin)) { why[2]++; continue; }
+        const double al = sqrt(axis_sum[0] * axis_sum[0] + axis_sum[1] * axis_sum[1] + axis_sum[2] * axis_sum[2]);
+        if (!(al > 0)) continue;
+        double a[3] = {axis_sum[0] / al, axis_sum[1] / al, axis_sum[2] / al}, omega = 0;
+        for (uint32_t t = 0; t < cnt; t++) omega = std::max(omega, acos(std::max(-1.0, std::min(1.0, nrm[t][0] * a[0] + nrm[t][1] * a[1] + nrm[t][2] * a[2]))));
+        const double psi = acos(kappa0) - omega - 0.02;
+        if (!(psi > 0.1)) { why[3]++; continue; }
+        const double mu = cos(psi);
+        double A[3] = {a[0] / mu, a[1] / mu, a[2] / mu}, Aq[3];
+        const uint32_t w = PackCone(A, Aq);
+        if (!w) continue;
+        const double aql = sqrt(Aq[0] * Aq[0] + Aq[1] * Aq[1] + Aq[2] * Aq[2]);
+        if (!(aql > 0)) continue;
+        bool cone_ok = true; // the guarantee of the STORED cone: |d.Aq| >= |d| keeps every |cos(n_T, d)| >= kappa0
+        for (uint32_t t = 0; t < cnt; t++) {
+            const double om = acos(std::max(-1.0, std::min(1.0, (nrm[t][0] * Aq[0] + nrm[t][1] * Aq[1] + nrm[t][2] * Aq[2]) / aql)));
+            if (!(acos(std::min(1.0, 1.0 / aql)) + om <= acos(kappa0) - 1e-3)) cone_ok = false;
+        }
+        if (!cone_ok) { why[4]++; continue; }
+        dn[i].parent = w;
+        n_ok++;
+    }
+    if (getenv("BHRT_DBG_BIG")) fprintf(stderr, "leaf skip: %zu of %zu leaves; fail: tri %zu, k0 %zu, far %zu, psi %zu, cone %zu; big %g\n", n_ok, n_leaves, why[0], why[1], why[2], why[3], why[4], big);
+    if (!n_ok) return;
+    o.skip_k0 = (float)(k0 * (1.0 + 1e-6)); o.skip_k1 = (float)(k1 * (1.0 + 1e-6)); o.skip_big = (float)(big * (1.0 - 1e-6)); o.skip_omax = 1024.f;
+}
+
 struct BlobWriter {
     std::vector<uint8_t> &b;
     explicit BlobWriter(std::vector<uint8_t> &v) : b(v) {}
@@ -1011,6 +1156,7 @@ int LoadSceneXml(const char *path, FlatScene &out, std::string &err, int bvh_dev
         o.off_ft = W.Append(m.ft.data(), m.ft.size() * 4);
         o.off_bvh = W.Append(m.bvh.data(), m.bvh.size() * sizeof(bhrt_bvh_node));
         o.off_elems = W.Append(m.elems.data(), m.elems.size() * 4);
+        std::vector<bhrt_bvh_node> dbvh;
         { // breadth-first renumbering for the device (children stay adjacent, first child even, like cyBVH.h:281-291)
             std::vector<bhrt_bvh_node> dn(m.bvh.size());
             memset(dn.data(), 0, sizeof(bhrt_bvh_node) * dn.size());
@@ -1032,7 +1178,7 @@ int LoadSceneXml(const char *path, FlatScene &out, std::string &err, int bvh_dev
                     order.push_back(c1); order.push_back(c1 + 1);
                 }
             }
-            o.off_dbvh = W.Append(dn.data(), dn.size() * sizeof(bhrt_bvh_node));
+            dbvh.swap(dn);
         }
         std::vector<bhrt_tri> tris(o.nf);
         for (uint32_t f = 0; f < o.nf; f++) {
@@ -1064,6 +1210,12 @@ int LoadSceneXml(const char *path, FlatScene &out, std::string &err, int bvh_dev
         o.off_leaf_tris = W.Append(leaf_tris.data(), leaf_tris.size() * sizeof(bhrt_tri));
         memcpy(o.bound_min, m.bound_min, 12);
         memcpy(o.bound_max, m.bound_max, 12);
+        {
+            std::vector<uint32_t> dparent;
+            ComputeLeafSkip(m, leaf_tris, dbvh, dparent, o); // the leaves' `parent` words become their cones; the links move to an array of their own
+            o.off_dbvh = W.Append(dbvh.data(), dbvh.size() * sizeof(bhrt_bvh_node));
+            o.off_dparent = W.Append(dparent.data(), dparent.size() * sizeof(uint32_t));
+        }
         o.bvh_nested = 1; // see bhrt_flat.h: checked, not assumed
         for (uint32_t n = 1; n < o.n_bvh_nodes && o.bvh_nested; n++) {
             const bhrt_bvh_node &pn = m.bvh[n];

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 MAGIC = 0x54524842
-VERSION = 9
+VERSION = 10
 BIGFLOAT = np.float32(1.0e30)
 
 OBJ_NONE, OBJ_SPHERE, OBJ_PLANE, OBJ_MESH = 0, 1, 2, 3
@@ -33,7 +33,8 @@ class Mesh(C.Structure):
                 ("off_v", C.c_uint64), ("off_vn", C.c_uint64), ("off_vt", C.c_uint64),
                 ("off_f", C.c_uint64), ("off_fn", C.c_uint64), ("off_ft", C.c_uint64),
                 ("off_bvh", C.c_uint64), ("off_elems", C.c_uint64), ("off_tris", C.c_uint64), ("off_dbvh", C.c_uint64), ("off_leaf_tris", C.c_uint64),
-                ("bound_min", C.c_float * 3), ("bound_max", C.c_float * 3), ("bvh_nested", C.c_uint32), ("pad0", C.c_uint32)]
+                ("bound_min", C.c_float * 3), ("bound_max", C.c_float * 3), ("bvh_nested", C.c_uint32), ("pad0", C.c_uint32),
+                ("off_dparent", C.c_uint64), ("skip_k0", C.c_float), ("skip_k1", C.c_float), ("skip_big", C.c_float), ("skip_omax", C.c_float)]
 
 
 class TexMap(C.Structure):

@@ -72,7 +72,10 @@ typedef struct bhrt_opts {
     int32_t photon_exact;     /* caustic gather of queries with >= 1000 photons inside the radius: 0 (default) = the same photon SET as
                                * LocatePhotons (cyPhotonMap.h:421-498) found by a wave-cooperative selection, sums in a fixed order (irradiance
                                * equal to a few ulp); 1 = the reference's candidate-heap history replayed lane by lane, identical bits, ~5x slower */
-    int32_t reserved[3];
+    int32_t leaf_skip;        /* 1 = the mesh walks leave out a box-missed LEAF sibling (TriObj.cpp:245-248,263-266,286-300) when its visit provably
+                               * accepts nothing (bhrt_flat.h: bhrt_mesh::skip_*; proof in scene_host.cpp::ComputeLeafSkip).  Same hit records either
+                               * way; 0 (default): on the scenes measured the test costs more instructions than the visits it saves */
+    int32_t reserved[2];
 } bhrt_opts;
 
 typedef struct bhrt_stats {

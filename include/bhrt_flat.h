@@ -20,7 +20,7 @@
 #include <stdint.h>
 
 #define BHRT_FLAT_MAGIC 0x54524842u /* "BHRT" */
-#define BHRT_FLAT_VERSION 9u
+#define BHRT_FLAT_VERSION 10u
 #define BHRT_MAX_NODE_DEPTH 8 /* scene-graph depth below the root the kernels support */
 #define BHRT_BIGFLOAT 1.0e30f  /* Scenes/scene.h:38 */
 
@@ -95,6 +95,13 @@ typedef struct bhrt_mesh {
                                           visit of a box-missed INNER sibling (TriObj.cpp:245-248,263-266) then ends at that node's own two box
                                           tests, and the traversal kernels may leave it out (device_trace.h) */
     uint32_t pad0;
+    uint64_t off_dparent;              /* uint32[n_bvh_nodes]: parent links of the breadth-first copy (the parent-link walks read them here) */
+    /* Skip of box-missed LEAF siblings ("leaf skip"; device_trace.h::leaf_skip).  In the breadth-first copy the `parent` word of a
+     * LEAF holds the leaf's packed normal cone instead (0 = the leaf is never skipped); these four are the mesh-wide constants of the test:
+     * a ray with max |o_i| <= skip_omax whose line misses the leaf box inflated by skip_k0 + skip_k1 * max|o_i|, passes through the box
+     * inflated by skip_big, and makes an angle with every triangle plane of the leaf that the cone bounds away from grazing cannot be
+     * accepted by IntersectTriangle (TriObj.cpp:68-189) for any triangle of the leaf.  skip_omax = 0: no leaf of this mesh qualifies. */
+    float skip_k0, skip_k1, skip_big, skip_omax;
 } bhrt_mesh;
 
 /* TextureMap = Transformation + texture (scene.h:364-386) */
