@@ -1,18 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s + wall-clock per frame of the HIP render path on BASELINE.json's configs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c3room|c4|c5|c1] [--no-configs]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c3room|c4|c5|c1] [--scaling weak|strong] [--no-configs]
 
 A "step" = one full frame of the workload through the hot path (camera rays -> wavefront
 trace/shade steps -> combine -> resolve [-> RCCL framebuffer gather when N > 1]).
-Headline workload (N = 1 default) = BASELINE.json configs[1]: tests/scenes/c2_glass.xml, 1920x1080, 16 spp,
-GI depth 3 (4 levels = "reflection/refraction depth 4"), internal bounces 16, keyed RNG seed 0.
-The same JSON line carries, under "configs", BASELINE's heavier configurations timed the same way with a few steps each:
-c3 (100,352-triangle mesh, 64 spp), c3room (the closed Cornell room of proj13.xml around the same mesh), c4 (3840x2160,
-32 spp per GPU = 256 spp on 8) and c5 (1 M caustic photons + k-NN gather, 64 spp) — each with its own `roofline`.
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); interleaved 32x32 tiles
-(tile t -> rank t mod N), spp scaled with N so per-GPU work is fixed (weak
-scaling), then one all_gather of the packed tile buffers over xGMI inside the timed region.
+Headline workload (N = 1 default) = BASELINE.json configs[2], the largest single-GPU 1080p configuration: tests/scenes/c3_mesh.xml
+(100,352-triangle mesh over a textured plane), 1920x1080, 64 spp, GI depth 3, internal bounces 16, keyed RNG seed 0 — the BVH walk
+north_star is about dominates it.  The same JSON line carries, under "configs", the other configurations timed the same way with a few
+steps each: c2 (BASELINE configs[1]: glass spheres, 16 spp, no mesh), c3room (the closed Cornell room of proj13.xml around the same
+mesh), c4 (3840x2160, 32 spp per GPU = 256 spp on 8) and c5 (1 M caustic photons + k-NN gather, 64 spp) — each with its own `roofline`.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); interleaved 32x32 tiles (tile t -> rank t mod N),
+one all_gather of the packed tile buffers over xGMI inside the timed region.  --scaling weak (default): spp scaled with N so per-GPU
+work is fixed; --scaling strong: BASELINE's own spp (64; 256 for c4) split over the ranks by tiles, total work fixed.
 `python bench.py --gpus N` without a torchrun environment starts the N ranks itself.
 The scene is resident in HBM before the timed region; outputs stay in HBM.
 
@@ -39,11 +39,14 @@ WORKLOADS = {
     # SURVEY.md 8(d) C3, second half: the closed room of Resource/Data/proj13.xml with the same mesh in the teapot's place
     "c3room": ("tests/scenes/c3_room.xml", 1920, 1080, 64, 3),
     # BASELINE config 4: the mesh scene at 3840x2160, 256 spp on 8 GPUs = 32 spp per GPU (weak scaling like every workload here)
-    "c4": ("tests/scenes/c4_mesh_4k.xml", 3840, 2160, 32, 3),
+    "c4": ("tests/scenes/c4_mesh_4k.xml", 3840, 2160, 32, 3),  # --scaling strong: 256 spp split by tiles (STRONG_SPP)
     # BASELINE config 5: caustic photon map, 1 M photons, k = 1000, r = 0.5 (photon build timed separately, see "photon_build_s")
     "c5": ("tests/scenes/c5_caustics_hd.xml", 1920, 1080, 64, 3),
 }
-SIDE_CONFIGS = ["c3", "c3room", "c4", "c5"]  # reported under "configs" beside the headline
+HEADLINE = "c3"
+SIDE_CONFIGS = ["c2", "c3room", "c4", "c5"]  # reported under "configs" beside the headline
+STRONG_SPP = {"c4": 256}  # --scaling strong: BASELINE's spp for the whole job (default: the workload's own per-GPU figure, e.g. 64 for c3 / c5)
+CPU_SAMPLE_SPP = {"c3": 32, "c3room": 2, "c4": 2, "c5": 2}  # cpu_baseline: samples per pixel of the bounded CPU sample (whole frame, fewer samples)
 BYTES_PER_CLOSEST_RAY = 56   # 32 B ray read + 24 B hit write
 BYTES_PER_SHADOW_RAY = 36    # 32 B read + 4 B visibility write
 BYTES_PER_SHADE_VERTEX = 92  # 24 hit + 32 ray read, 12 radiance, 24 next-ray writes
@@ -60,8 +63,9 @@ def ensure_assets():
         gen_mesh.generate(mesh, 224)
 
 
-def cpu_baseline(scene_path, spp, gi):
-    """Reference CPU path on one whole step of the same workload (the full frame), on this box's host cores.
+def cpu_baseline(scene_path, spp, gi, full_spp=None):
+    """Reference CPU path on a bounded sample of the same workload — the whole frame at `spp` samples per pixel (of the workload's
+    `full_spp`: every pixel, fewer samples; ~10-30 s of CPU work) — on this box's host cores.
 
     kind "reference": the reference itself (oracle/_ref/ref_harness, compiled from /root/reference in the dev
     container) run as one single-threaded process per row band (its RNG is a process-global); the harness reports its
@@ -83,7 +87,8 @@ def cpu_baseline(scene_path, spp, gi):
                   want_samples=False)
     port_s = time.time() - t0
     rays = ro["stats"].closest_rays + ro["stats"].shadow_rays
-    sample = f"one whole step: {W}x{H} x {spp} spp ({W * H * spp} camera samples, {rays} rays)"
+    sample = (f"one whole step: {W}x{H} x {spp} spp ({W * H * spp} camera samples, {rays} rays)" if not full_spp or full_spp == spp else
+              f"the whole {W}x{H} frame at {spp} of the workload's {full_spp} samples per pixel ({W * H * spp} camera samples, {rays} rays)")
     out = {"value": rays / port_s / 1e6, "unit": "Mrays/s", "cores": cores, "host_cores": host_cores, "kind": "port", "sample": sample,
            "seconds": port_s}
     harness = os.path.join(ROOT, "oracle/_ref/ref_harness")
@@ -124,7 +129,7 @@ def pmc_profile(workload):
         return {}
 
 
-def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=None):
+def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=None, extras=False):
     """Times `steps` frames of workload `name` (barrier + synchronize on both sides, max over ranks)."""
     import torch
     import bhraytracer_amd as B
@@ -135,7 +140,10 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
     sc = B.Scene(scene_path)
     assert (sc.width, sc.height) == (W, H), "scene size differs from the workload table"
     sc.upload(ctx["local_rank"])
-    spp = spp1 * N  # weak scaling: per-GPU sample count is fixed
+    if ctx.get("scaling", "weak") == "strong":  # total work fixed: BASELINE's spp for the whole job, the frame split over the ranks by tiles
+        spp = STRONG_SPP.get(name, spp1)
+    else:
+        spp = spp1 * N  # weak scaling: per-GPU sample count is fixed
     opts = B.default_opts(spp=spp, gi_bounces=gi, internal_bounces=16, seed=0, rank=rank, world_size=N, tile_size=TILE)
     opts.samples_per_pass = samples_per_pass
     opts.timers = timers if timers is not None else (0 if name == "c2" else 1)
@@ -196,6 +204,25 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
         rays_total, closest_total, samples_total = (float(x) for x in rr.tolist())
     else:
         rays_total, closest_total, samples_total = float(rays_local), float(agg["closest_rays"]), float(agg["camera_samples"])
+    extra = None
+    if extras and rank == 0:
+        # the two lines SURVEY.md 8(d) asks for beside the frame time: the device-to-host copy of the frame (RGB8 + float radiance, pinned
+        # destination) and the PNG encode (RenderImage::SaveImage, scene.h:628-644 -> bhrt_save_png), each timed on its own after the run
+        import numpy as np
+        rgb, rad = bufs[0][0], bufs[0][1]
+        h_rgb, h_rad = torch.empty(rgb.shape, dtype=rgb.dtype).pin_memory(), torch.empty(rad.shape, dtype=rad.dtype).pin_memory()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        h_rgb.copy_(rgb, non_blocking=True); h_rad.copy_(rad, non_blocking=True)
+        torch.cuda.synchronize()
+        d2h_ms = (time.perf_counter() - t0) * 1e3
+        with tempfile.TemporaryDirectory() as td:
+            t0 = time.perf_counter()
+            B.save_png(os.path.join(td, "frame.png"), h_rgb.numpy())
+            png_ms = (time.perf_counter() - t0) * 1e3
+            png_bytes = os.path.getsize(os.path.join(td, "frame.png"))
+        extra = {"d2h_ms": d2h_ms, "d2h_bytes": int(h_rgb.numel() + 4 * h_rad.numel()), "png_encode_ms": png_ms, "png_bytes": png_bytes,
+                 "note": "not part of ms_per_step: the timed region leaves the frame in HBM"}
     sc_n_meshes = sc.info.n_meshes
     sc.close()  # frees this workload's HBM (scene + up to ~190 GB of wavefront workspace) before the next one
     del bufs
@@ -226,7 +253,7 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
                 "k_trace_shadow": "k_trace_shadow(_park) + k_shadow_mesh (any-hit group of one wave step)", "k_shade": "k_shade",
                 "k_photon_gather": "k_photon_gather_* + cell sort (caustic gather of one pass)"}
     res = {
-        "workload": f"{os.path.basename(scene_rel)} {W}x{H}, {spp} spp ({spp1} per GPU), GI depth {gi}, "
+        "workload": f"{os.path.basename(scene_rel)} {W}x{H}, {spp} spp ({'%g' % (spp / N)} per GPU, {ctx.get('scaling', 'weak')} scaling), GI depth {gi}, "
                     f"internal bounces 16, keyed RNG seed 0, {TILE}x{TILE} interleaved tiles over {N} GPU(s)",
         "steps": steps, "warmup": warmup,
         "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": elapsed / steps * 1e3,
@@ -238,15 +265,31 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
         "roofline": {"bound": "hbm", "kernel": dom, "kernels_timed": group_of[dom], "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": prof.get(dom + "_bytes_per_launch"),
                      "avg_launch_ms": avg_launch_s * 1e3, "units_per_launch": units_per_launch, "bytes_per_unit": bpu,
+                     # what actually limits the kernel (PMC passes of this round, profiles/pmc_traffic.json): the share of the SIMDs' VALU issue
+                     # slots it uses, the lanes enabled in an average VALU instruction, and their product = the share of the chip's lane-slots that do work
+                     "limited_by": "valu issue at low lane use + dependent fetches (not HBM): see valu_issue_frac / valu_lanes_per_inst",
                      "valu_issue_frac": prof.get(dom + "_valu_issue_frac"),
-                     "note": "scene is cache-resident; traversal/shading are latency- and VALU-issue-bound, not HBM-bound (DESIGN.md 4)"},
+                     "valu_lanes_per_inst": prof.get(dom + "_valu_lanes_per_inst"),
+                     "valu_lane_frac": (prof.get(dom + "_valu_issue_frac") * prof.get(dom + "_valu_lanes_per_inst") / 64.0)
+                     if prof.get(dom + "_valu_issue_frac") and prof.get(dom + "_valu_lanes_per_inst") else None,
+                     "note": "`bound`/`frac` are the HBM roofline the contract asks for (algorithmic bytes of SURVEY.md 8(d) over the kernel group's "
+                             "HIP-event time); the scene is cache-resident and these kernels are not HBM-bound (DESIGN.md 4)"},
     }
+    if dom == "k_photon_gather" and res["roofline"]["traffic"] and avg_launch_s > 0:
+        # the photon map is cache-resident: 24 B per examined node is an ALGORITHMIC rate served from L2 / Infinity Cache.  `frac` is the share of
+        # the HBM peak that the MEASURED traffic (FETCH_SIZE + WRITE_SIZE passes) amounts to; the algorithmic figure keeps a key of its own.
+        res["roofline"]["achieved_algorithmic"] = achieved
+        res["roofline"]["frac_algorithmic"] = achieved / HBM_PEAK_GBPS
+        res["roofline"]["achieved"] = res["roofline"]["traffic"] / avg_launch_s / 1e9
+        res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBPS
     if dom == "k_shade" and fused_camera:
         # The camera step of a mesh-free scene is ONE kernel: k_shade traces its camera rays itself, so the launches timed here also do SURVEY's
         # closest-hit unit (56 B) for every camera sample.  `frac` above stays the conservative figure (shade vertices only); this one adds them.
         with_trace = (bpu * n_units + BYTES_PER_CLOSEST_RAY * agg["camera_samples"]) / launches / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         res["roofline"]["achieved_incl_camera_trace"] = with_trace
         res["roofline"]["frac_incl_camera_trace"] = with_trace / HBM_PEAK_GBPS
+    if extra:
+        res["wall_clock_extra"] = extra
     if photon_build_s is not None:
         res["photon"] = {"build_s": photon_build_s, "gather_s_per_frame": gather_s / steps,
                          "heavy_pass_s_per_frame": agg.get("seconds_photon_heavy", 0.0) / steps,
@@ -274,14 +317,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = spp x N, per-GPU work fixed (default); strong = BASELINE's spp (64; 256 for c4) split over the ranks by tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip the 'configs' object (c3, c3room, c4, c5)")
-    ap.add_argument("--configs", default=",".join(SIDE_CONFIGS), help="workloads reported under 'configs' (default run of the headline workload c2 only)")
+    ap.add_argument("--configs", default=",".join(SIDE_CONFIGS), help="workloads reported under 'configs' (default run of the headline workload only)")
     ap.add_argument("--config-steps", type=int, default=3)
     ap.add_argument("--config-warmup", type=int, default=1)
     ap.add_argument("--samples-per-pass", type=int, default=0, help="camera samples in flight per wavefront pass (0 = library default)")
     ap.add_argument("--timers", type=int, default=None, help="bhrt_opts.timers: 0 = HIP events around k_shade only (default for c2, whose dominant kernel it is), 1 = around every kernel group (default otherwise; costs ~0.2 ms of event gaps per frame), -1 = none")
+    ap.add_argument("--cpu-sample-spp", type=int, default=0, help="samples per pixel of the cpu_baseline leg (0 = the bounded default of the workload)")
     ap.add_argument("--photons", type=int, default=1000000, help="photon budget of workload c5 (MAX_CausticPhotonCount, Main.cpp:53)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: all ranks share cuda:0 and the gather goes through gloo on host copies, "
@@ -319,14 +365,14 @@ def main():
         ensure_assets()
     if N > 1:
         dist.barrier()
-    ctx = {"rank": rank, "local_rank": local_rank, "N": N, "dev": dev, "dist": dist, "rehearse": args.rehearse_on_one_gpu}
+    ctx = {"rank": rank, "local_rank": local_rank, "N": N, "dev": dev, "dist": dist, "rehearse": args.rehearse_on_one_gpu, "scaling": args.scaling}
 
-    head = run_workload(args.workload, args.steps, args.warmup, ctx, args.photons, args.samples_per_pass, args.timers)
+    head = run_workload(args.workload, args.steps, args.warmup, ctx, args.photons, args.samples_per_pass, args.timers, extras=True)
     configs = {}
-    if args.workload == "c2" and not args.no_configs:
+    if args.workload == HEADLINE and not args.no_configs:
         for name in [c for c in args.configs.split(",") if c]:
             try:  # a side workload that fails is reported as such; the headline line is printed regardless
-                configs[name] = run_workload(name, args.config_steps, args.config_warmup, ctx, args.photons)
+                configs[name] = run_workload(name, 20 if name == "c2" else args.config_steps, 3 if name == "c2" else args.config_warmup, ctx, args.photons)
             except Exception as e:  # noqa: BLE001
                 configs[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
 
@@ -339,7 +385,7 @@ def main():
             "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -352,17 +398,23 @@ def main():
         }
         if "photon" in head:
             out["photon"] = head["photon"]
+        if "wall_clock_extra" in head:
+            out["wall_clock_extra"] = head["wall_clock_extra"]
         if configs:
             out["configs"] = configs
         if N == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(os.path.join(ROOT, scene_rel), spp1, gi)
+            out["cpu_baseline"] = cpu_baseline(os.path.join(ROOT, scene_rel), args.cpu_sample_spp or CPU_SAMPLE_SPP.get(args.workload, spp1), gi, full_spp=spp1)
         print(json.dumps(out), flush=True)
     if N > 1:
         try:
             dist.barrier()
             dist.destroy_process_group()
-        except Exception:  # noqa: BLE001 — the line is out; a broken group (a side workload failed on some rank) must not turn into a failed run
+        except Exception:  # noqa: BLE001 — the line is out; a broken group must not hide the exit code below
             pass
+    failed = [k for k, v in configs.items() if isinstance(v, dict) and "error" in v]
+    if failed:  # the line is printed with the error in it, but a side workload that breaks fails the run
+        print(f"bench.py: side workload(s) failed: {failed}", file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

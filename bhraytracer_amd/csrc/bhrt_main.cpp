@@ -4,7 +4,7 @@
 // :141, GIBounceCount :130, INTERNAL_REFLECTION_BOUNCE :41) as command-line options.
 //
 //   bhrt render <scene.xml> [-o out.png] [--spp N] [--gi N] [--bounces N] [--seed S] [--no-jitter] [--no-gamma]
-//               [--device D | --gpus N] [--rank R --world N] [--tile T] [--radiance out.f32]
+//               [--device D | --gpus N [--rehearse]] [--rank R --world N] [--tile T] [--radiance out.f32] [--leaf-skip] [--photon-exact]
 //               [--photons N] [--photon-file map.dat] [--photon-out map.dat]     (USE_PhotonMap, Main.cpp:51,53,194,383)
 //   bhrt info   <scene.xml>
 //
@@ -14,6 +14,8 @@
 // (xGMI) moves every GPU's block to all of them, bhrt_tiles_unpack_dev rebuilds the frame, GPU 0's copy is saved.  The caustic
 // photon map is emitted in disjoint emission-index ranges on the N GPUs (bhrt_photon_emit_range) and installed on every one
 // (bhrt_photon_install): the same map as on one GPU.  --gpus 1 runs the same code over a one-device communicator.
+// --gpus N --rehearse: the same N threads, rendezvous points, per-rank renders, packs and unpacks with every rank on device 0 and the
+// ncclAllGather replaced by N device-to-device copies — what a one-GPU box can run of the N > 1 control flow (tests/test_cli.py).
 // Without --gpus: one device, no RCCL involved (--rank / --world then render that rank's tiles only, for process-per-GPU launchers).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -47,6 +49,21 @@ struct Args {
     uint32_t photons = 0;
     bhrt_opts o;
     int device = 0, gpus = 0;
+    bool rehearse = false; // --rehearse: the N ranks of --gpus N all on device 0, the all-gather as N device-to-device copies (no RCCL)
+};
+
+// Everything render_multi owns besides the caller's scene: released on every way out (the early returns included).
+struct MultiGuard {
+    std::vector<ncclComm_t> comms;
+    std::vector<bhrt_scene *> clones; // scenes[1..N-1]
+    bool aborted = false;
+    ~MultiGuard()
+    {
+        for (ncclComm_t c : comms)
+            if (c) { if (aborted) ncclCommAbort(c); else ncclCommDestroy(c); }
+        for (bhrt_scene *s : clones)
+            if (s) bhrt_scene_free(s);
+    }
 };
 
 // BeginRender over N GPUs of this node; rgb / rad: the whole frame on the host (rad may be empty)
@@ -55,26 +72,36 @@ static int render_multi(bhrt_scene *first, const Args &A, const bhrt_info &info,
 {
     const int N = A.gpus, W = info.width, H = info.height, tile = A.o.tile_size > 0 ? A.o.tile_size : 32;
     int have = 0;
-    if (bhrt_device_count(&have) || have < N) { fprintf(stderr, "bhrt: --gpus %d but %d device(s) visible\n", N, have); return 1; }
+    if (bhrt_device_count(&have) || have < (A.rehearse ? 1 : N)) { fprintf(stderr, "bhrt: --gpus %d but %d device(s) visible\n", N, have); return 1; }
     std::vector<int> devs(N);
-    for (int r = 0; r < N; r++) devs[r] = r;
-    std::vector<ncclComm_t> comms(N);
-    if (ncclCommInitAll(comms.data(), N, devs.data()) != ncclSuccess) { fprintf(stderr, "bhrt: ncclCommInitAll over %d devices failed\n", N); return 1; }
+    for (int r = 0; r < N; r++) devs[r] = A.rehearse ? 0 : r;
+    MultiGuard G;
+    if (!A.rehearse) {
+        G.comms.assign(N, nullptr);
+        if (ncclCommInitAll(G.comms.data(), N, devs.data()) != ncclSuccess) { fprintf(stderr, "bhrt: ncclCommInitAll over %d devices failed\n", N); return 1; }
+    }
     std::vector<bhrt_scene *> scenes(N, nullptr);
     scenes[0] = first;
-    for (int r = 1; r < N; r++)
+    G.clones.assign(N, nullptr);
+    for (int r = 1; r < N; r++) {
         if (bhrt_scene_clone(first, &scenes[r])) return fail("scene clone");
+        G.clones[r] = scenes[r];
+    }
     const size_t bb = bhrt_tiles_block_bytes(W, H, tile, N), npx = (size_t)W * H;
     stats.assign(N, bhrt_stats());
     std::atomic<bool> failed(false);
 
-    // ---- caustic photon map over the N GPUs (BuildCausticPhotonMap, Main.cpp:342-386): batches of emissions, GPU r takes the r-th
-    // slice of every batch, the host strings the slices together in emission order and every GPU installs the first `photons` records
+    // ---- caustic photon map over the N GPUs (BuildCausticPhotonMap, Main.cpp:342-386): batches of 2^20 emissions — the batch of the
+    // single-GPU build, cut like bhraytracer_amd/dist.py::photon_build_sharded cuts it (slice r = blocks [256 B r / N, 256 B (r + 1) / N) of
+    // the batch's B = 4096 blocks of 256), so that every N stops after the same number of emissions when a scene runs out of its emission
+    // budget —, GPU r emits the r-th slice of every batch, the host strings the slices together in emission order and every GPU installs the
+    // first `photons` records.
     if (!A.photon_file.empty()) {
         for (int r = 0; r < N; r++)
             if (bhrt_scene_upload(scenes[r], devs[r]) || bhrt_photon_import(scenes[r], A.photon_file.c_str(), 0)) return fail("photon import");
     } else if (A.photons) {
-        const uint32_t per_rank = ((1u << 20) / (uint32_t)N) / 256 * 256;
+        const uint32_t batch = 1u << 20, blocks = batch / 256;
+        if ((uint32_t)N > blocks) { fprintf(stderr, "bhrt: --gpus %d: more ranks than emission blocks per batch\n", N); return 1; }
         std::vector<uint8_t> kept;
         uint64_t e0 = 0, total = 0;
         const uint64_t budget = (uint64_t)A.photons * 4096ull + (1ull << 24);
@@ -85,10 +112,11 @@ static int render_multi(bhrt_scene *first, const Args &A, const bhrt_info &info,
             for (int r = 0; r < N; r++)
                 th.emplace_back([&, r]() {
                     HOST_CHECK(bhrt_scene_upload(scenes[r], devs[r]), "upload");
-                    uint32_t cap = 4 * per_rank;
+                    const uint32_t lo = 256u * (uint32_t)((uint64_t)blocks * (uint64_t)r / (uint64_t)N), hi = 256u * (uint32_t)((uint64_t)blocks * (uint64_t)(r + 1) / (uint64_t)N);
+                    uint32_t cap = std::max(4 * (hi - lo), 4096u);
                     for (int attempt = 0; attempt < 2; attempt++) { // "photons_out too small" reports the size it needs
                         part[r].resize((size_t)cap * 24);
-                        if (bhrt_photon_emit_range(scenes[r], &A.o, 0, e0 + (uint64_t)r * per_rank, per_rank, part[r].data(), cap, &cnt[r]) == 0) return;
+                        if (bhrt_photon_emit_range(scenes[r], &A.o, 0, e0 + lo, hi - lo, part[r].data(), cap, &cnt[r]) == 0) return;
                         if (cnt[r] <= cap) break;
                         cap = cnt[r];
                     }
@@ -98,7 +126,7 @@ static int render_multi(bhrt_scene *first, const Args &A, const bhrt_info &info,
             for (auto &t : th) t.join();
             if (failed.load()) return 1;
             for (int r = 0; r < N; r++) { kept.insert(kept.end(), part[r].begin(), part[r].begin() + (size_t)cnt[r] * 24); total += cnt[r]; }
-            e0 += (uint64_t)per_rank * N;
+            e0 += batch;
         }
         if (total == 0) { fprintf(stderr, "bhrt: photon map: no photon reached a photon surface\n"); return 1; }
         const uint32_t n = (uint32_t)std::min<uint64_t>(total, A.photons);
@@ -108,10 +136,13 @@ static int render_multi(bhrt_scene *first, const Args &A, const bhrt_info &info,
     }
     if ((A.o.photon_map || A.photons || !A.photon_file.empty()) && !A.photon_out.empty() && bhrt_photon_export(scenes[0], A.photon_out.c_str())) return fail("photon export");
 
-    // ---- the frame: one host thread per GPU.  The threads agree on failure at two rendezvous points (after set-up, after the render),
-    // so either all of them enter the collective or none does: a rank missing from an all-gather would hang the others.
+    // ---- the frame: one host thread per GPU.  The threads agree on failure at three rendezvous points — after set-up, after the render, after
+    // the pack — so either all of them enter the collective or none does: a rank missing from an all-gather would hang the others.  Inside the
+    // collective a thread never blocks in a stream synchronise: it polls its stream and the failure flag, and when a peer has failed it
+    // aborts its communicator (ncclCommAbort) and leaves.
     std::vector<double> gather_s(N, 0.0);
-    std::atomic<int> ready(0), rendered(0);
+    std::vector<uint8_t *> mine_of(N, nullptr); // --rehearse: where every rank's packed block lies (all on device 0)
+    std::atomic<int> ready(0), rendered(0), packed(0), exchanged(0);
     auto rendezvous = [&](std::atomic<int> &c) { c.fetch_add(1); while (c.load() < N) std::this_thread::yield(); return !failed.load(); };
     std::vector<std::thread> th;
     for (int r = 0; r < N; r++)
@@ -143,9 +174,35 @@ static int render_multi(bhrt_scene *first, const Args &A, const bhrt_info &info,
             if (bhrt_render_dev(scenes[r], &o, d_rgb, d_rad, &stats[r], nullptr)) { fprintf(stderr, "bhrt: GPU %d: BeginRender: %s\n", r, bhrt_last_error()); failed.store(true); }
             if (!rendezvous(rendered)) { release(); return; }
             const auto t0 = std::chrono::steady_clock::now();
-            auto exchange = [&]() {
+            auto pack = [&]() {
                 HOST_CHECK(bhrt_tiles_pack_dev(d_rgb, d_rad, W, H, tile, r, N, d_mine, s), "pack");
-                HOST_CHECK(ncclAllGather(d_mine, d_all, bb, ncclUint8, comms[r], s) != ncclSuccess, "ncclAllGather");
+                HOST_CHECK(hipStreamSynchronize(s), "sync");
+                mine_of[r] = d_mine;
+            };
+            pack();
+            if (getenv("BHRT_TEST_FAIL_PACK") && atoi(getenv("BHRT_TEST_FAIL_PACK")) == r) { fprintf(stderr, "bhrt: GPU %d: pack failed (test knob)\n", r); failed.store(true); }
+            if (!rendezvous(packed)) { release(); return; } // a rank whose pack failed keeps everybody out of the collective
+            // waits for the stream without blocking in it: a peer's failure is seen within a poll
+            auto wait_stream = [&]() -> bool {
+                for (;;) {
+                    const hipError_t q = hipStreamQuery(s);
+                    if (q == hipSuccess) return true;
+                    if (q != hipErrorNotReady) { fprintf(stderr, "bhrt: GPU %d: stream: %s\n", r, hipGetErrorString(q)); failed.store(true); }
+                    if (failed.load()) {
+                        if (!A.rehearse) { ncclCommAbort(G.comms[r]); G.comms[r] = nullptr; }
+                        return false;
+                    }
+                    std::this_thread::yield();
+                }
+            };
+            auto exchange = [&]() {
+                if (A.rehearse) { // the all-gather of N ranks on ONE device: every rank copies every block into its own receive buffer
+                    for (int k = 0; k < N; k++) HOST_CHECK(hipMemcpyAsync(d_all + (size_t)k * bb, mine_of[k], bb, hipMemcpyDeviceToDevice, s), "copy of a peer's block");
+                } else if (ncclAllGather(d_mine, d_all, bb, ncclUint8, G.comms[r], s) != ncclSuccess) {
+                    fprintf(stderr, "bhrt: GPU %d: ncclAllGather failed\n", r);
+                    failed.store(true);
+                }
+                if (!wait_stream()) return;
                 HOST_CHECK(bhrt_tiles_unpack_dev(d_all, W, H, tile, N, d_rgb, d_rad, s), "unpack");
                 HOST_CHECK(hipStreamSynchronize(s), "sync");
                 gather_s[r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -155,12 +212,12 @@ static int render_multi(bhrt_scene *first, const Args &A, const bhrt_info &info,
                 }
             };
             exchange();
+            rendezvous(exchanged); // --rehearse: nobody frees a block a peer may still be copying
             release();
         });
     for (auto &t : th) t.join();
     gather_seconds = *std::max_element(gather_s.begin(), gather_s.end());
-    for (int r = 0; r < N; r++) ncclCommDestroy(comms[r]);
-    for (int r = 1; r < N; r++) bhrt_scene_free(scenes[r]);
+    G.aborted = failed.load();
     return failed.load() ? 1 : 0;
 }
 
@@ -189,6 +246,7 @@ int main(int argc, char **argv)
         else if (s == "--photon-exact") o.photon_exact = 1;
         else if (s == "--device") A.device = atoi(next());
         else if (s == "--gpus") A.gpus = atoi(next());
+        else if (s == "--rehearse") A.rehearse = true;
         else if (s == "--rank") o.rank = atoi(next());
         else if (s == "--world") o.world_size = atoi(next());
         else if (s == "--tile") o.tile_size = atoi(next());
@@ -230,7 +288,7 @@ int main(int argc, char **argv)
                    (unsigned long long)(per[r].closest_rays + per[r].shadow_rays), per[r].seconds_total);
         }
         st.seconds_total = slowest;
-        printf("%d GPU(s): frame %.3f s on the slowest GPU, RCCL tile gather %.4f s, %.3f s wall incl. set-up\n", A.gpus, slowest, gather_s, wall);
+        printf("%d GPU(s): frame %.3f s on the slowest GPU, %s tile gather %.4f s, %.3f s wall incl. set-up\n", A.gpus, slowest, A.rehearse ? "rehearsed (device-to-device)" : "RCCL", gather_s, wall);
     } else {
         if (bhrt_scene_upload(scene, A.device)) return fail("upload");
         if (!A.photon_file.empty()) { // a cached photon pass

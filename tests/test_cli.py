@@ -63,3 +63,47 @@ def test_cli_photon_map_over_the_multi_gpu_path(load_scene, O, B, tmp_path):
     # the cached photon pass: --photon-file
     _run(["render", xml, "-o", str(tmp_path / "c.png"), "--spp", "2", "--gi", "2", "--photon-file", a, "--gpus", "1"], SCENES)
     assert np.array_equal(_png(str(tmp_path / "c.png")), _png(str(tmp_path / "a.png")))
+
+
+@pytest.mark.gpu
+def test_cli_eight_ranks_rehearsed_on_one_gpu(tmp_path):
+    """`bhrt render --gpus 8 --rehearse`: the N > 1 control flow of the C++ host — eight host threads with a scene handle each, the three
+    rendezvous points, per-rank bhrt_render_dev of the interleaved tiles, bhrt_tiles_pack_dev, the exchange (N device-to-device copies in the
+    place of ncclAllGather: a one-GPU box has no peers), bhrt_tiles_unpack_dev — on BASELINE config 4's 3840x2160 frame at 1 spp: the PNG and
+    the radiance are the single-rank render's, byte for byte."""
+    from conftest import ensure_mesh
+    ensure_mesh(224)
+    xml = os.path.join(SCENES, "c4_mesh_4k.xml")
+    a, b = tmp_path / "a", tmp_path / "b"
+    out = _run(["render", xml, "-o", f"{a}.png", "--radiance", f"{a}.f32", "--spp", "1", "--gi", "3", "--seed", "5", "--gpus", "8", "--rehearse"], SCENES)
+    assert "8 GPU(s)" in out and "rehearsed" in out and out.count("GPU ") >= 8
+    _run(["render", xml, "-o", f"{b}.png", "--radiance", f"{b}.f32", "--spp", "1", "--gi", "3", "--seed", "5", "--device", "0"], SCENES)
+    assert open(f"{a}.png", "rb").read() == open(f"{b}.png", "rb").read()
+    assert open(f"{a}.f32", "rb").read() == open(f"{b}.f32", "rb").read() and os.path.getsize(f"{a}.f32") == 3840 * 2160 * 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [8, 3])
+def test_cli_photon_map_of_n_rehearsed_ranks(n, tmp_path):
+    """The caustic map emitted by N ranks (every batch of 2^20 emissions cut into N index ranges like dist.py::photon_build_sharded cuts it —
+    N = 3 does not divide the batch's 4096 blocks), strung together on the host and installed on every rank, is the single-GPU map file for
+    file, and the frame gathered from the N ranks is the single-rank frame."""
+    xml = os.path.join(SCENES, "c5_caustics.xml")
+    a, b = tmp_path / "a", tmp_path / "b"
+    args = ["--spp", "2", "--gi", "2", "--photons", "30000"]
+    out = _run(["render", xml, "-o", f"{a}.png", "--radiance", f"{a}.f32", "--photon-out", f"{a}.dat", "--gpus", str(n), "--rehearse"] + args, SCENES)
+    assert f"on {n} GPU(s)" in out
+    _run(["render", xml, "-o", f"{b}.png", "--radiance", f"{b}.f32", "--photon-out", f"{b}.dat"] + args, SCENES)
+    assert open(f"{a}.dat", "rb").read() == open(f"{b}.dat", "rb").read() and os.path.getsize(f"{a}.dat") == 30000 * 24
+    assert open(f"{a}.png", "rb").read() == open(f"{b}.png", "rb").read()
+    assert open(f"{a}.f32", "rb").read() == open(f"{b}.f32", "rb").read()
+
+
+@pytest.mark.gpu
+def test_cli_a_rank_that_fails_before_the_collective_does_not_hang_the_others(tmp_path):
+    """A rank whose pack fails (test knob BHRT_TEST_FAIL_PACK = rank) keeps every rank out of the exchange: the program ends with an error
+    instead of leaving N - 1 threads in an all-gather that never completes."""
+    xml = os.path.join(SCENES, "c2_glass_small.xml")
+    r = subprocess.run([CLI, "render", xml, "-o", str(tmp_path / "x.png"), "--spp", "1", "--gpus", "4", "--rehearse"], cwd=SCENES, capture_output=True, text=True,
+                       timeout=120, env=dict(os.environ, BHRT_TEST_FAIL_PACK="2"))
+    assert r.returncode == 1 and "pack failed" in r.stderr and not (tmp_path / "x.png").exists()

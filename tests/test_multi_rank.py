@@ -80,7 +80,27 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "2 spp (1 per GPU)" in d["config"]["workload"] and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "2 spp (1 per GPU, weak scaling)" in d["config"]["workload"] and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_of_the_headline_over_four_ranks():
+    """`python bench.py --gpus 4 --scaling strong` on the headline workload (BASELINE config 3: 64 spp for the WHOLE job, the frame split over the
+    ranks by tiles): four ranks rehearsed on the one GPU of the box (a box allows at most six GPU processes; the exchange goes through gloo), the
+    line says which scaling it measured and counts the rays of all ranks — the same rays as one rank rendering the whole frame."""
+    import json, subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    common = ["--workload", "c3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-configs", "--samples-per-pass", str(1 << 22)]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearse-on-one-gpu", "--scaling", "strong"] + common,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and "64 spp (16 per GPU, strong scaling)" in d["config"]["workload"]
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, env=env, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
+    d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert d1["n_gpus"] == 1 and d["config"]["rays_per_frame"] == d1["config"]["rays_per_frame"]
+    assert d["config"]["camera_samples_per_frame"] == d1["config"]["camera_samples_per_frame"] == 1920 * 1080 * 64
 
 
 _RCCL_WORLD_OF_ONE = r"""

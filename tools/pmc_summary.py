@@ -126,6 +126,8 @@ def main():
                 e["valu_issue_frac"] = e["SQ_INSTS_VALU"] * 4.0 / (1024 * sec * 2.4e9)
                 name = {"k_trace_mesh_stream": "k_trace_closest", "k_trace_mesh": "k_trace_closest", "k_shadow_mesh": "k_trace_shadow", "k_photon_gather_fast": "k_photon_gather"}.get(k, k)
                 per_launch.setdefault(name + "_valu_issue_frac", e["valu_issue_frac"])
+                if e.get("valu_lanes_per_inst"):
+                    per_launch.setdefault(name + "_valu_lanes_per_inst", e["valu_lanes_per_inst"])  # bench.py: roofline.valu_lane_frac = issue x lanes / 64
         json.dump(out, open(os.path.join(dst, f"{wl}_pmc_one_frame.json"), "w"), indent=1)
         traffic[wl] = per_launch
     traffic["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/pmc_workload.py (one frame), "
