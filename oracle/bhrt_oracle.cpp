@@ -595,12 +595,13 @@ template <class M> struct Textures {
         float x = width * u.x, y = height * u.y;
         int ix = (int)x, iy = (int)y;
         float fx = x - ix, fy = y - iy;
-        if (ix < 0) ix -= (ix / width - 1) * width;
-        if (ix >= width) ix -= (ix / width) * width;
+        // (the products wrap in 32 bits like the reference's compiled code does for a huge |x|: unsigned arithmetic, no signed overflow)
+        if (ix < 0) ix = (int)((uint32_t)ix - (uint32_t)(ix / width - 1) * (uint32_t)width);
+        if (ix >= width) ix = (int)((uint32_t)ix - (uint32_t)(ix / width) * (uint32_t)width);
         int ixp = ix + 1;
         if (ixp >= width) ixp -= width;
-        if (iy < 0) iy -= (iy / height - 1) * height;
-        if (iy >= height) iy -= (iy / height) * height;
+        if (iy < 0) iy = (int)((uint32_t)iy - (uint32_t)(iy / height - 1) * (uint32_t)height);
+        if (iy >= height) iy = (int)((uint32_t)iy - (uint32_t)(iy / height) * (uint32_t)height);
         int iyp = iy + 1;
         if (iyp >= height) iyp -= height;
         auto texel = [&](int yy, int xx) { const uint8_t *p = data + 3 * ((size_t)yy * width + xx); return Color(p[0] / 255.0f, p[1] / 255.0f, p[2] / 255.0f); };
