@@ -1300,12 +1300,12 @@ __global__ void __launch_bounds__(kBlock) k_photon_emit(DevScene S, uint32_t see
     counts[i] = emit_photon_path<kGlobal>(S, seed, e0 + i, plights, n_plights, sum_intensity, tmp + (size_t)i * cap, cap);
 }
 // stable compaction in emission order: path i's photons go to out[1 + offsets[i] + k] (slot 0 stays unused)
-__global__ void __launch_bounds__(kBlock) k_photon_compact(const DPhoton *tmp, uint32_t cap, const uint32_t *counts, const uint32_t *offsets, uint32_t E,
+__global__ void __launch_bounds__(kBlock) k_photon_compact(const DPhoton *tmp, uint32_t cap, const uint32_t *counts, const uint32_t *offsets, uint32_t base, uint32_t E,
                                                             uint32_t max_photons, DPhoton *out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E) return;
-    const uint32_t c = counts[i], off = offsets[i];
+    const uint32_t c = counts[i], off = (uint32_t)min((uint64_t)base + offsets[i], (uint64_t)max_photons); // base: photons of the earlier batches
     for (uint32_t k = 0; k < c && k < cap; k++)
         if (off + k < max_photons) out[1 + off + k] = tmp[(size_t)i * cap + k];
 }
@@ -1469,6 +1469,9 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t *data, uint32_
     const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
     for (uint32_t k = 0; k < kScanPerThread; k++) if (base + k < n) data[base + k] += add;
 }
+} // namespace bhrt
+#include "device_photon_build.h"
+namespace bhrt {
 __global__ void __launch_bounds__(kBlock) k_gather_cell_scatter(uint32_t q0, uint32_t cnt, const uint32_t *cell_of, uint32_t *cell_cursor, uint32_t *order)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2709,60 +2712,124 @@ try {
     return BHRT_OK;
 } catch (...) { return bhrt::AbiException(); }
 
-// D->h_photons (balanced, heap order, slot 0 unused) -> HBM: the 24-byte records, the decoded hot/cold copy the gather
-// walks (PhotonMapDev) and the bounds of the photon positions.
-static int InstallPhotonMap(DeviceState *D)
+// PrepareForIrradianceEstimation (cyPhotonMap.h:236-258) on the device (device_photon_build.h): d_in = n + 1 records in emission order, slot 0
+// zero, powers scaled; *d_out = a new buffer with the balanced map in heap order (the caller owns it).
+static int BalanceOnDevice(DeviceState *D, const DPhoton *d_in, uint32_t n, DPhoton **d_out)
 {
-    const uint32_t n = (uint32_t)D->h_photons.size() - 1;
-    if (D->d_photons) { (void)hipFree(D->d_photons); D->d_photons = nullptr; D->n_photons = 0; }
-    HIP_CHECK(hipMalloc(&D->d_photons, ((size_t)n + 1) * sizeof(DPhoton)));
-    HIP_CHECK(hipMemcpy(D->d_photons, D->h_photons.data(), ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyHostToDevice));
+    struct Bufs {
+        uint32_t *id = nullptr, *la = nullptr, *lb = nullptr, *count = nullptr; float *key = nullptr; PbSeg *seg[2] = {nullptr, nullptr}; DPhoton *out = nullptr;
+        ~Bufs() { (void)hipFree(id); (void)hipFree(la); (void)hipFree(lb); (void)hipFree(count); (void)hipFree(key); (void)hipFree(seg[0]); (void)hipFree(seg[1]); (void)hipFree(out); }
+    } b;
+    const size_t n2 = (size_t)n + 2, max_segs = (size_t)n / 2 + 2;
+    HIP_CHECK(hipMalloc(&b.id, n2 * 4)); HIP_CHECK(hipMalloc(&b.la, n2 * 4)); HIP_CHECK(hipMalloc(&b.lb, n2 * 4)); HIP_CHECK(hipMalloc(&b.key, n2 * 4));
+    HIP_CHECK(hipMalloc(&b.count, 4)); HIP_CHECK(hipMalloc(&b.seg[0], max_segs * sizeof(PbSeg))); HIP_CHECK(hipMalloc(&b.seg[1], max_segs * sizeof(PbSeg)));
+    HIP_CHECK(hipMalloc(&b.out, ((size_t)n + 1) * sizeof(DPhoton)));
+    HIP_CHECK(hipMemsetAsync(b.out, 0, ((size_t)n + 1) * sizeof(DPhoton), D->stream));
+    hipLaunchKernelGGL(k_pb_root, dim3(1), dim3(1024), 0, D->stream, d_in, n, b.seg[0], b.id);
+    uint32_t count = 1;
+    int cur = 0;
+    for (int level = 0; count > 0; level++) {
+        if (level > 64) { SetError("photon balance: more than 64 levels"); return BHRT_ERR_HIP; }
+        HIP_CHECK(hipMemsetAsync(b.count, 0, 4, D->stream));
+        const uint64_t avg = (uint64_t)n / count; // segments of a level have nearly equal sizes: the workgroup that suits them
+        if (avg > 2048) hipLaunchKernelGGL(k_pb_level<1024>, dim3(count), dim3(1024), 0, D->stream, d_in, b.id, b.key, b.la, b.lb, b.seg[cur], count, b.seg[cur ^ 1], b.count, b.out);
+        else if (avg > 64) hipLaunchKernelGGL(k_pb_level<256>, dim3(count), dim3(256), 0, D->stream, d_in, b.id, b.key, b.la, b.lb, b.seg[cur], count, b.seg[cur ^ 1], b.count, b.out);
+        else hipLaunchKernelGGL(k_pb_level<64>, dim3(count), dim3(64), 0, D->stream, d_in, b.id, b.key, b.la, b.lb, b.seg[cur], count, b.seg[cur ^ 1], b.count, b.out);
+        HIP_CHECK(hipMemcpyAsync(&count, b.count, 4, hipMemcpyDeviceToHost, D->stream));
+        HIP_CHECK(hipStreamSynchronize(D->stream));
+        if (count > max_segs) { SetError("photon balance: segment list overflow"); return BHRT_ERR_HIP; }
+        cur ^= 1;
+    }
+    *d_out = b.out;
+    b.out = nullptr;
+    return BHRT_OK;
+}
+
+// A balanced map (heap order, slot 0 unused) that lies in HBM -> installed for the gather: the 24-byte records stay where they are (the device
+// owns them from here on), the decoded hot / cold copy the gather walks (PhotonMapDev), the direction bounds of the top levels and the bounds of
+// the positions are formed on the device.  The host copy (bhrt_photon_get / _export) is fetched when somebody asks for it.
+static int InstallPhotonMapDev(DeviceState *D, DPhoton *d_balanced, uint32_t n)
+{
+    if (D->d_photons && D->d_photons != d_balanced) (void)hipFree(D->d_photons);
+    D->d_photons = d_balanced;
     D->n_photons = n;
+    D->h_photons.clear();
     if (D->d_ph_hot) (void)hipFree(D->d_ph_hot);
     if (D->d_ph_cold) (void)hipFree(D->d_ph_cold);
     D->d_ph_hot = nullptr; D->d_ph_cold = nullptr;
     HIP_CHECK(hipMalloc(&D->d_ph_hot, ((size_t)n + 1) * sizeof(float4)));
     HIP_CHECK(hipMalloc(&D->d_ph_cold, ((size_t)n + 1) * 2 * sizeof(float4)));
     hipLaunchKernelGGL(k_photon_expand, dim3((n + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, D->d_photons, n, D->d_ph_hot, D->d_ph_cold);
-    HIP_CHECK(hipStreamSynchronize(D->stream));
     D->pm.hot = D->d_ph_hot; D->pm.cold = D->d_ph_cold; D->pm.n = (int)n; D->pm.half = (int)n / 2 - 1;
-    { // PhotonMapDev::dbox: bounds of the directions of the photons LocatePhotons reaches below every node (it recurses only below `half`), bottom up
-        std::vector<float> lo(((size_t)n + 1) * 3), hi(((size_t)n + 1) * 3);
-        const int half = D->pm.half;
-        for (size_t i = n; i >= 1; i--) {
-            DPhoton p;
-            memcpy(&p, &D->h_photons[i], sizeof p);
-            const V3 d = photon_direction(p); // the arithmetic k_photon_expand uses (IEEE divisions, integer square root)
-            float l3[3] = {d.x, d.y, d.z}, h3[3] = {d.x, d.y, d.z};
-            if ((int)i < half)
-                for (size_t c = 2 * i; c <= 2 * i + 1 && c <= n; c++)
-                    for (int k = 0; k < 3; k++) { l3[k] = std::min(l3[k], lo[c * 3 + k]); h3[k] = std::max(h3[k], hi[c * 3 + k]); }
-            for (int k = 0; k < 3; k++) { lo[i * 3 + k] = l3[k]; hi[i * 3 + k] = h3[k]; }
+    { // PhotonMapDev::dbox, bottom up, one heap level per launch
+        struct Tmp { float *lo = nullptr, *hi = nullptr, *b6 = nullptr; ~Tmp() { (void)hipFree(lo); (void)hipFree(hi); (void)hipFree(b6); } } t;
+        HIP_CHECK(hipMalloc(&t.lo, ((size_t)n + 1) * 3 * sizeof(float)));
+        HIP_CHECK(hipMalloc(&t.hi, ((size_t)n + 1) * 3 * sizeof(float)));
+        HIP_CHECK(hipMalloc(&t.b6, 6 * sizeof(float)));
+        int top = 0;
+        while ((2ull << top) <= (uint64_t)n) top++; // level of node n
+        for (int L = top; L >= 0; L--) {
+            const uint32_t first = 1u << L, last = (uint32_t)std::min<uint64_t>((2ull << L) - 1, n);
+            hipLaunchKernelGGL(k_pb_dbox_level, dim3((last - first + 256) / 256), dim3(256), 0, D->stream, D->d_photons, n, D->pm.half, first, last, t.lo, t.hi);
         }
         const uint32_t nb = std::min<uint32_t>(n + 1, 1u << BHRT_DBOX_LEVELS);
-        std::vector<float4> box((size_t)nb * 2, make_float4(0, 0, 0, 0));
-        for (uint32_t i = 1; i < nb; i++) {
-            box[2 * (size_t)i] = make_float4(lo[(size_t)i * 3], lo[(size_t)i * 3 + 1], lo[(size_t)i * 3 + 2], 0.f);
-            box[2 * (size_t)i + 1] = make_float4(hi[(size_t)i * 3], hi[(size_t)i * 3 + 1], hi[(size_t)i * 3 + 2], 0.f);
-        }
         if (D->d_ph_dbox) (void)hipFree(D->d_ph_dbox);
         D->d_ph_dbox = nullptr;
-        HIP_CHECK(hipMalloc(&D->d_ph_dbox, box.size() * sizeof(float4)));
-        HIP_CHECK(hipMemcpy(D->d_ph_dbox, box.data(), box.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMalloc(&D->d_ph_dbox, (size_t)nb * 2 * sizeof(float4)));
+        hipLaunchKernelGGL(k_pb_dbox_pack, dim3((nb + 255) / 256), dim3(256), 0, D->stream, t.lo, t.hi, nb, D->d_ph_dbox);
         D->pm.dbox = D->d_ph_dbox; D->pm.n_dbox = (int)nb;
+        hipLaunchKernelGGL(k_pb_bounds, dim3(1), dim3(1024), 0, D->stream, D->d_photons, n, t.b6);
+        float b6[6];
+        HIP_CHECK(hipMemcpyAsync(b6, t.b6, sizeof b6, hipMemcpyDeviceToHost, D->stream));
+        HIP_CHECK(hipStreamSynchronize(D->stream));
+        for (int k = 0; k < 3; k++) { D->pm.lo[k] = b6[k]; D->pm.hi[k] = b6[3 + k]; }
     }
-    for (int k = 0; k < 3; k++) { D->pm.lo[k] = BHRT_BIGFLOAT; D->pm.hi[k] = -BHRT_BIGFLOAT; }
-    for (size_t i = 1; i <= n; i++)
-        for (int k = 0; k < 3; k++) {
-            D->pm.lo[k] = std::min(D->pm.lo[k], D->h_photons[i].pos[k]);
-            D->pm.hi[k] = std::max(D->pm.hi[k], D->h_photons[i].pos[k]);
-        }
+    return BHRT_OK;
+}
+// the same for a map that lies on the host (a file: bhrt_photon_import)
+static int InstallPhotonMap(DeviceState *D)
+{
+    const uint32_t n = (uint32_t)D->h_photons.size() - 1;
+    DPhoton *d = nullptr;
+    HIP_CHECK(hipMalloc(&d, ((size_t)n + 1) * sizeof(DPhoton)));
+    const hipError_t e = hipMemcpy(d, D->h_photons.data(), ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); HIP_CHECK(e); }
+    std::vector<HostPhoton> keep;
+    keep.swap(D->h_photons);
+    const int rc = InstallPhotonMapDev(D, d, n);
+    D->h_photons.swap(keep); // the host copy is already there
+    return rc;
+}
+// host copy of the installed map, fetched on demand (bhrt_photon_get / bhrt_photon_export)
+static int EnsureHostPhotons(DeviceState *D)
+{
+    if (!D->h_photons.empty() || !D->d_photons || !D->n_photons) return BHRT_OK;
+    D->h_photons.assign((size_t)D->n_photons + 1, HostPhoton());
+    HIP_CHECK(hipMemcpy(D->h_photons.data(), D->d_photons, ((size_t)D->n_photons + 1) * sizeof(DPhoton), hipMemcpyDeviceToHost));
+    memset(&D->h_photons[0], 0, sizeof(HostPhoton));
+    return BHRT_OK;
+}
+// the balance of n + 1 emission-order records in HBM: on the device, or (BHRT_PHOTON_BALANCE_HOST=1: the tests' second opinion) by photon_host.cpp
+static int BalanceRecords(DeviceState *D, const DPhoton *d_in, uint32_t n, DPhoton **d_out)
+{
+    static const bool host = getenv("BHRT_PHOTON_BALANCE_HOST") && atoi(getenv("BHRT_PHOTON_BALANCE_HOST")) != 0;
+    if (!host) return BalanceOnDevice(D, d_in, n, d_out);
+    std::vector<HostPhoton> h((size_t)n + 1);
+    HIP_CHECK(hipMemcpy(h.data(), d_in, ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyDeviceToHost));
+    memset(&h[0], 0, sizeof(HostPhoton));
+    BalancePhotons(h);
+    DPhoton *d = nullptr;
+    HIP_CHECK(hipMalloc(&d, ((size_t)n + 1) * sizeof(DPhoton)));
+    const hipError_t e = hipMemcpy(d, h.data(), ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); HIP_CHECK(e); }
+    *d_out = d;
     return BHRT_OK;
 }
 
-// Emission + stable compaction + ScalePhotonPowers + balance; `out` = the balanced records (slot 0 unused).
+// Emission + stable compaction + ScalePhotonPowers + balance, all in HBM: *d_balanced = the balanced records (n + 1, slot 0 unused; the caller
+// owns the buffer).  Per batch of emissions only two words reach the host (the largest count of a path, the photons of the batch).
 // global_map: BuildPhotonMap / TracePhotonRay / RandomPhotonBounce instead of the caustic variants.
-static int BuildPhotons(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, bool global_map, std::vector<HostPhoton> &out)
+static int BuildPhotons(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, bool global_map, DPhoton **d_balanced, uint32_t *n_out)
 {
     int rc = EnsureUploaded(scene);
     if (rc) return rc;
@@ -2781,8 +2848,8 @@ static int BuildPhotons(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_p
     for (int32_t i : pl) sum += key(i);
 
     struct Bufs { // freed on every return path, HIP_CHECK's included
-        DPhoton *out = nullptr, *tmp = nullptr; uint32_t *counts = nullptr, *offsets = nullptr; int32_t *pl = nullptr;
-        ~Bufs() { (void)hipFree(out); (void)hipFree(tmp); (void)hipFree(counts); (void)hipFree(offsets); (void)hipFree(pl); }
+        DPhoton *out = nullptr, *tmp = nullptr; uint32_t *counts = nullptr, *offsets = nullptr, *sums = nullptr, *stats = nullptr; int32_t *pl = nullptr;
+        ~Bufs() { (void)hipFree(out); (void)hipFree(tmp); (void)hipFree(counts); (void)hipFree(offsets); (void)hipFree(sums); (void)hipFree(stats); (void)hipFree(pl); }
     } bufs;
     DPhoton *&d_out = bufs.out, *&d_tmp = bufs.tmp;
     uint32_t *&d_counts = bufs.counts, *&d_offsets = bufs.offsets;
@@ -2796,41 +2863,40 @@ static int BuildPhotons(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_p
     HIP_CHECK(hipMalloc(&d_pl, pl.size() * sizeof(int32_t)));
     HIP_CHECK(hipMemcpy(d_pl, pl.data(), pl.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_CHECK(hipMalloc(&d_tmp, (size_t)E * cap * sizeof(DPhoton)));
-    std::vector<uint32_t> counts(E), offsets(E);
+    const uint32_t n_tiles = (E + kScanTile - 1) / kScanTile;
+    HIP_CHECK(hipMalloc(&bufs.sums, n_tiles * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&bufs.stats, 2 * sizeof(uint32_t)));
     uint64_t e0 = 0, stored = 0;
     const uint64_t emission_budget = (uint64_t)max_photons * 4096ull + (1ull << 24);
     while (stored < max_photons && e0 < emission_budget) {
         if (global_map) hipLaunchKernelGGL(k_photon_emit<true>, dim3(E / kBlock), dim3(kBlock), 0, D->stream, D->S, opts->seed, e0, E, d_pl, (int)pl.size(), sum, d_tmp, cap, d_counts);
         else hipLaunchKernelGGL(k_photon_emit<false>, dim3(E / kBlock), dim3(kBlock), 0, D->stream, D->S, opts->seed, e0, E, d_pl, (int)pl.size(), sum, d_tmp, cap, d_counts);
-        HIP_CHECK(hipMemcpyAsync(counts.data(), d_counts, E * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
+        // where every path's photons go: exclusive prefix of the counts, on the device; two words come back
+        HIP_CHECK(hipMemcpyAsync(d_offsets, d_counts, E * sizeof(uint32_t), hipMemcpyDeviceToDevice, D->stream));
+        hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, d_offsets, E, bufs.sums);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, D->stream, bufs.sums, n_tiles);
+        hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, d_offsets, E, bufs.sums);
+        HIP_CHECK(hipMemsetAsync(bufs.stats, 0, 2 * sizeof(uint32_t), D->stream));
+        hipLaunchKernelGGL(k_pb_batch_stats, dim3(64), dim3(256), 0, D->stream, d_counts, d_offsets, E, bufs.stats);
+        uint32_t stats[2];
+        HIP_CHECK(hipMemcpyAsync(stats, bufs.stats, sizeof stats, hipMemcpyDeviceToHost, D->stream));
         HIP_CHECK(hipStreamSynchronize(D->stream));
-        uint32_t maxc = 0;
-        for (uint32_t i = 0; i < E; i++) maxc = std::max(maxc, counts[i]);
-        if (maxc > cap) { // a path stored more than `cap` photons: redo this batch with room for all of them
+        if (stats[0] > cap) { // a path stored more than `cap` photons: redo this batch with room for all of them
             (void)hipFree(d_tmp);
             d_tmp = nullptr;
-            cap = maxc;
+            cap = stats[0];
             HIP_CHECK(hipMalloc(&d_tmp, (size_t)E * cap * sizeof(DPhoton)));
             continue;
         }
-        uint64_t run = stored;
-        for (uint32_t i = 0; i < E; i++) { offsets[i] = (uint32_t)std::min<uint64_t>(run, max_photons); run += counts[i]; }
-        HIP_CHECK(hipMemcpyAsync(d_offsets, offsets.data(), E * sizeof(uint32_t), hipMemcpyHostToDevice, D->stream));
-        hipLaunchKernelGGL(k_photon_compact, dim3(E / kBlock), dim3(kBlock), 0, D->stream, d_tmp, cap, d_counts, d_offsets, E, max_photons, d_out);
-        HIP_CHECK(hipStreamSynchronize(D->stream));
-        stored = run;
+        hipLaunchKernelGGL(k_photon_compact, dim3(E / kBlock), dim3(kBlock), 0, D->stream, d_tmp, cap, d_counts, d_offsets, (uint32_t)std::min<uint64_t>(stored, max_photons), E, max_photons, d_out);
+        stored += stats[1];
         e0 += E;
     }
     const uint32_t n = (uint32_t)std::min<uint64_t>(stored, max_photons);
     if (n == 0) { SetError("photon map: no photon reached a photon surface"); return BHRT_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_photon_scale, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, d_out, n, 1.f / (float)(int)n); // Main.cpp:380
-    // PrepareForIrradianceEstimation on the host (cyPhotonMap.h:236-258), then back to HBM
-    out.assign((size_t)n + 1, HostPhoton());
-    HIP_CHECK(hipMemcpyAsync(out.data(), d_out, ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyDeviceToHost, D->stream));
-    HIP_CHECK(hipStreamSynchronize(D->stream));
-    memset(&out[0], 0, sizeof(HostPhoton));
-    BalancePhotons(out);
-    return BHRT_OK;
+    *n_out = n;
+    return BalanceRecords(D, d_out, n, d_balanced); // PrepareForIrradianceEstimation (cyPhotonMap.h:236-258)
 }
 
 // ---- multi-GPU photon build: emission is keyed by the emission index, so ranks emit disjoint index ranges,
@@ -2882,7 +2948,7 @@ try {
     if (total == 0) return BHRT_OK;
     HIP_CHECK(hipMalloc(&b.out, ((size_t)total + 1) * sizeof(DPhoton)));
     HIP_CHECK(hipMemcpyAsync(b.offsets, offsets.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, D->stream));
-    hipLaunchKernelGGL(k_photon_compact, dim3(count / kBlock), dim3(kBlock), 0, D->stream, b.tmp, cap, b.counts, b.offsets, count, (uint32_t)total, b.out);
+    hipLaunchKernelGGL(k_photon_compact, dim3(count / kBlock), dim3(kBlock), 0, D->stream, b.tmp, cap, b.counts, b.offsets, 0u, count, (uint32_t)total, b.out);
     HIP_CHECK(hipMemcpyAsync(photons_out, b.out + 1, (size_t)total * sizeof(DPhoton), hipMemcpyDefault, D->stream)); // host or device destination
     HIP_CHECK(hipStreamSynchronize(D->stream));
     return BHRT_OK;
@@ -2899,28 +2965,24 @@ try {
     HIP_CHECK(hipMalloc(&d, ((size_t)n + 1) * sizeof(DPhoton)));
     hipError_t e = hipMemset(d, 0, sizeof(DPhoton));
     if (e == hipSuccess) e = hipMemcpy(d + 1, records, (size_t)n * sizeof(DPhoton), hipMemcpyDefault); // host or device source
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_photon_scale, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, d, n, 1.f / (float)(int)n);
-        D->h_photons.assign((size_t)n + 1, HostPhoton());
-        e = hipMemcpyAsync(D->h_photons.data(), d, ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyDeviceToHost, D->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(D->stream);
-    }
+    if (e != hipSuccess) { (void)hipFree(d); HIP_CHECK(e); }
+    hipLaunchKernelGGL(k_photon_scale, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, d, n, 1.f / (float)(int)n);
+    DPhoton *bal = nullptr;
+    rc = BalanceRecords(D, d, n, &bal); // the records stay in HBM from the caller's buffer to the installed map
     (void)hipFree(d);
-    HIP_CHECK(e);
-    memset(&D->h_photons[0], 0, sizeof(HostPhoton));
-    BalancePhotons(D->h_photons);
-    return InstallPhotonMap(D);
+    if (rc) return rc;
+    return InstallPhotonMapDev(D, bal, n);
 } catch (...) { return bhrt::AbiException(); }
 
 int bhrt_photon_build(bhrt_scene *scene, const bhrt_opts *opts, uint32_t max_photons, uint32_t *n_stored)
 try {
     if (!scene) { SetError("null scene"); return BHRT_ERR_ARG; }
-    std::vector<HostPhoton> balanced;
-    int rc = BuildPhotons(scene, opts, max_photons, false, balanced);
+    DPhoton *bal = nullptr;
+    uint32_t n = 0;
+    int rc = BuildPhotons(scene, opts, max_photons, false, &bal, &n);
     if (rc) return rc;
     DeviceState *D = scene->dev;
-    D->h_photons.swap(balanced);
-    rc = InstallPhotonMap(D);
+    rc = InstallPhotonMapDev(D, bal, n);
     if (rc) return rc;
     if (n_stored) *n_stored = D->n_photons;
     return BHRT_OK;
@@ -2930,10 +2992,14 @@ int bhrt_photon_build_global(bhrt_scene *scene, const bhrt_opts *opts, uint32_t 
                              const char *dat_path)
 try {
     if (!scene) { SetError("null scene"); return BHRT_ERR_ARG; }
-    std::vector<HostPhoton> balanced;
-    int rc = BuildPhotons(scene, opts, max_photons, true, balanced);
+    DPhoton *bal = nullptr;
+    uint32_t n = 0;
+    int rc = BuildPhotons(scene, opts, max_photons, true, &bal, &n);
     if (rc) return rc;
-    const uint32_t n = (uint32_t)balanced.size() - 1;
+    std::vector<HostPhoton> balanced((size_t)n + 1);
+    const hipError_t ce = hipMemcpy(balanced.data(), bal, ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyDeviceToHost);
+    (void)hipFree(bal);
+    HIP_CHECK(ce);
     if (n_stored) *n_stored = n;
     if (photons_out) {
         if (capacity < n) { SetError("photon buffer too small"); return BHRT_ERR_ARG; }
@@ -3002,7 +3068,9 @@ int bhrt_photon_gather_host(bhrt_scene *scene, const float *p, const float *nrm,
 
 int bhrt_photon_get(const bhrt_scene *scene, void *photons_out, uint32_t capacity, uint32_t *n)
 try {
-    if (!scene || !scene->dev || scene->dev->h_photons.empty()) { SetError("photon map: nothing built"); return BHRT_ERR_ARG; }
+    if (!scene || !scene->dev || !scene->dev->n_photons) { SetError("photon map: nothing built"); return BHRT_ERR_ARG; }
+    const int hrc = EnsureHostPhotons(scene->dev);
+    if (hrc) return hrc;
     const uint32_t have = scene->dev->n_photons;
     if (n) *n = have;
     if (photons_out) {
@@ -3014,7 +3082,9 @@ try {
 
 int bhrt_photon_export(const bhrt_scene *scene, const char *dat_path)
 try {
-    if (!scene || !scene->dev || scene->dev->h_photons.empty() || !dat_path) { SetError("photon map: nothing to export"); return BHRT_ERR_ARG; }
+    if (!scene || !scene->dev || !scene->dev->n_photons || !dat_path) { SetError("photon map: nothing to export"); return BHRT_ERR_ARG; }
+    const int hrc = EnsureHostPhotons(scene->dev);
+    if (hrc) return hrc;
     FILE *fp = fopen(dat_path, "wb"); // fwrite(GetPhotons(), sizeof(Photon), NumPhotons(), fp), Main.cpp:383-385
     if (!fp) { SetError(std::string("cannot write ") + dat_path); return BHRT_ERR_IO; }
     const size_t n = scene->dev->n_photons;

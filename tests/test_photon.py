@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import same_bits
+from conftest import SCENES, same_bits
 
 
 def check_photon_bytes(mine, ref, half=None):
@@ -384,3 +384,63 @@ def test_the_list_locate_photons_ends_with_is_a_set_rule(O):
         assert cnt[k] == len(expect) and np.array_equal(np.sort(idx[k][:cnt[k]]), np.uint32(expect)), k
         assert np.float32(d2max[k]) == np.float32(bound), k
     assert heavy >= 20
+
+
+def _records(pos, rng):
+    """(n, 24) uint8 photon records (cyPhotonMap.h:72-90) at the given positions, everything else random, power 0 (ScalePhotonPowers keeps it)."""
+    n = len(pos)
+    rec = rng.integers(0, 256, (n, 24), dtype=np.uint8)
+    rec[:, :12] = np.ascontiguousarray(pos, np.float32).view(np.uint8).reshape(n, 12)
+    rec[:, 12:16] = 0
+    return rec
+
+
+@pytest.mark.gpu
+def test_device_balance_equals_the_oracle_on_tie_heavy_maps(B, load_scene, O):
+    """k_pb_level (device_photon_build.h): PrepareForIrradianceEstimation / BalanceSegment (cyPhotonMap.h:236-328) on the device.  The balanced map
+    depends on the exact swap sequence of every Hoare partition wherever keys are equal (and deep segments split along the axis of an INHERITED
+    box, where a caustic on a floor has nothing but equal keys), so the maps here are made of ties: a floor (one z), a coarse grid (few distinct
+    values per axis), duplicates of a handful of points, all-equal points, -0 beside +0, and the small sizes around the median rule's cases.
+    Every byte of the installed map equals the oracle's restatement of the reference's routine."""
+    sc = B.Scene(os.path.join(SCENES, "c5_caustics.xml"))
+    sc.upload(0)
+    rng = np.random.default_rng(11)
+    cases = []
+    for n in (1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 17, 31, 33, 64, 65, 100, 1000, 4097, 50000, 300000):
+        kind = n % 5
+        if kind == 0:    # a floor: z equal everywhere, x / y continuous
+            p = rng.uniform(-3, 3, (n, 3)); p[:, 2] = 0.25
+        elif kind == 1:  # coarse grid: 4 values per axis
+            p = rng.integers(0, 4, (n, 3)) * 0.5 - 1.0
+        elif kind == 2:  # duplicates of a few points, zeros of both signs
+            base = rng.normal(size=(5, 3)); base[0] = [0.0, -0.0, 0.0]; base[1] = [-0.0, 0.0, -0.0]
+            p = base[rng.integers(0, 5, n)]
+        elif kind == 3:  # everything equal
+            p = np.tile(rng.normal(size=(1, 3)), (n, 1))
+        else:            # continuous cloud with a dense cluster
+            p = rng.normal(size=(n, 3)); p[: n // 2] = p[: n // 2] * 1e-3 + 2.0
+        cases.append(_records(p, rng))
+    cases.append(_records(np.repeat(rng.uniform(-1, 1, (1000, 3)), 100, axis=0), rng))  # 100 copies of each of 1000 points, grouped
+    for rec in cases:
+        n = sc.photon_install(rec)
+        got = sc.photon_get()
+        want = O.photon_balance(rec)
+        assert got.shape == want.shape == (n, 24) and np.array_equal(got, want), n
+
+
+@pytest.mark.gpu
+def test_device_balance_and_host_routine_agree_on_a_built_map(tmp_path):
+    """Second opinion: the same 200 k-photon build with the balance done by the host routine (photon_host.cpp, BHRT_PHOTON_BALANCE_HOST=1: the
+    records make the round trip through the host) and on the device (default: they never leave HBM) — the same file, byte for byte."""
+    import subprocess
+    from conftest import ROOT
+    cli = os.path.join(ROOT, "bhraytracer_amd", "bhrt")
+    xml = os.path.join(SCENES, "c5_caustics.xml")
+    outs = []
+    for host in ("0", "1"):
+        dat = tmp_path / f"m{host}.dat"
+        r = subprocess.run([cli, "render", xml, "-o", str(tmp_path / f"m{host}.png"), "--spp", "1", "--gi", "1", "--photons", "200000", "--photon-out", str(dat)],
+                           cwd=SCENES, capture_output=True, text=True, timeout=600, env=dict(os.environ, BHRT_PHOTON_BALANCE_HOST=host))
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        outs.append(open(dat, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) == 200000 * 24
