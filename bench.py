@@ -297,7 +297,10 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
                          "heavy_queries_per_frame": agg.get("photon_heavy_queries", 0) / steps,
                          "wave_queries_per_frame": agg.get("photon_wave_queries", 0) / steps,
                          "exact_replay_queries_per_frame": agg.get("photon_exact_queries", 0) / steps,
-                         "nodes_visited_per_frame": agg.get("photon_nodes_visited", 0) / steps}
+                         "nodes_visited_per_frame": agg.get("photon_nodes_visited", 0) / steps,
+                         # the lane pass alone: kd nodes examined per answered query against the photons the answer is made of (the floor of any walk)
+                         "lane_pass_nodes_per_query": agg.get("photon_lane_nodes", 0) / max(1, agg.get("photon_lane_queries", 0)),
+                         "lane_pass_found_per_query": agg.get("photon_found", 0) / max(1, agg.get("photon_lane_queries", 0))}
     return res
 
 

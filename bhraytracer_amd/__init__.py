@@ -32,7 +32,7 @@ class Opts(C.Structure):
     _fields_ = [("spp", C.c_int32), ("gi_bounces", C.c_int32), ("internal_bounces", C.c_int32), ("seed", C.c_uint32),
                 ("jitter", C.c_int32), ("gamma", C.c_int32), ("photon_map", C.c_int32),
                 ("rank", C.c_int32), ("world_size", C.c_int32), ("tile_size", C.c_int32),
-                ("samples_per_pass", C.c_int32), ("timers", C.c_int32), ("photon_exact", C.c_int32), ("leaf_skip", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("samples_per_pass", C.c_int32), ("timers", C.c_int32), ("photon_exact", C.c_int32), ("leaf_skip", C.c_int32), ("photon_radius", C.c_float), ("reserved", C.c_int32 * 1)]
 
 
 class Stats(C.Structure):
@@ -44,7 +44,7 @@ class Stats(C.Structure):
                 ("seconds_photon_gather", C.c_double), ("seconds_photon_heavy", C.c_double),
                 ("photon_queries", C.c_uint64), ("photon_heavy_queries", C.c_uint64), ("photon_wave_queries", C.c_uint64),
                 ("photon_exact_queries", C.c_uint64), ("photon_nodes_visited", C.c_uint64), ("deferred_rays", C.c_uint64),
-                ("reserved", C.c_double * 4)]
+                ("photon_lane_queries", C.c_uint64), ("photon_lane_nodes", C.c_uint64), ("photon_found", C.c_uint64), ("reserved", C.c_double * 1)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
@@ -65,7 +65,7 @@ EXPORTS = [
     "bhrt_photon_get", "bhrt_photon_export", "bhrt_photon_import", "bhrt_photon_build_global", "bhrt_save_png", "bhrt_math_eval_dev",
     "bhrt_tiles_block_bytes", "bhrt_tiles_pack_dev", "bhrt_tiles_unpack_dev",
     "bhrt_first_hit", "bhrt_first_hit_dev", "bhrt_zbuffer_image_dev", "bhrt_color_image_dev",
-    "bhrt_scene_load_xml_ex", "bhrt_bvh_build", "bhrt_photon_emit_range", "bhrt_photon_install", "bhrt_scene_clone", "bhrt_host_alloc", "bhrt_host_free", "bhrt_photon_gather_host_ex",
+    "bhrt_scene_load_xml_ex", "bhrt_bvh_build", "bhrt_photon_emit_range", "bhrt_photon_install", "bhrt_scene_clone", "bhrt_host_alloc", "bhrt_host_free", "bhrt_photon_gather_host_ex", "bhrt_scene_knob",
 ]
 
 
@@ -234,6 +234,10 @@ class Scene:
         n = C.c_uint32(0)
         _check(lib().bhrt_photon_build(self._h, C.byref(opts), int(max_photons), C.byref(n)))
         return n.value
+
+    def knob(self, name: str, value: int):
+        """Test knobs ("frame_cap", "gather_lane_budget"; 0 = off): which internal path a render takes, never its result (bhrt_scene_knob)."""
+        _check(lib().bhrt_scene_knob(self._h, name.encode(), int(value)))
 
     def photon_get(self) -> np.ndarray:
         """Balanced (heap-order) photon array as (n, 24) uint8 records (cyPhotonMap.h:72-90)."""

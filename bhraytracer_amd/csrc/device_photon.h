@@ -120,6 +120,7 @@ __device__ inline uint32_t emit_photon_path(const DevScene &S, uint32_t seed, ui
 {
     DRng g;
     bhrt_photon_stream(seed, emission, &g.key, &g.ctr);
+    g.wrap = BHRT_PHOTON_WINDOW_MASK;
     // light choice, Main.cpp:365-371
     float rnd = g.rnd01();
     int li = 0;
@@ -266,13 +267,14 @@ __device__ inline void photon_finish(V3 sumI, V3 sumD, float d2max, V3 &irrad, V
 // met: the caller redoes this query with photon_estimate_heap (the sums then run in heap-array order); 3 = more than
 // `budget` photons visited without an answer: the caller hands the query to a whole wave (k_photon_gather_select), so
 // that one lane's long walk (a dense cluster inside the radius, most of it rejected) does not hold up its launch.
-__device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 normal, float radius, int budget, V3 &irrad, V3 &direction, uint32_t &visited)
+// found: the photons accepted so far (inside the radius, on the right side) — what the estimate is made of; bhrt_stats.photon_found
+__device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 normal, float radius, int budget, V3 &irrad, V3 &direction, uint32_t &visited, int &found)
 {
     irrad = v3(0, 0, 0);
     direction = v3(0, 0, 0);
+    found = 0;
     if (M.n <= 0 || photon_outside_bounds(M, pos, radius)) return 0;
     const float d2max = radius * radius;
-    int found = 0;
     V3 sumI = v3(0, 0, 0), sumD = v3(0, 0, 0);
     PhotonWalk w;
     int node;

@@ -197,7 +197,11 @@ __device__ inline V3 sample_environment(const DevScene &S, const bhrt_texcolor &
 // ---------------------------------------------------------------------------------------------- RNG + samplers
 struct DRng {
     uint32_t key, ctr;
-    __device__ int rand() { return bhrt_rand31(key, ctr++); }
+    // wrap: the bits of the counter that advance.  All of them for a (pixel, sample, path, section) stream; the low 16 for a photon emission, which
+    // owns a 2^16-draw window of its key (bhrt_photon_stream): a degenerate path whose rejection loops run to BHRT_MAXLOOP then re-reads its OWN
+    // window instead of running through the windows of the emissions behind it — two emissions never read the same (key, counter) pair.
+    uint32_t wrap = 0xffffffffu;
+    __device__ int rand() { const uint32_t c = ctr; ctr = (c & ~wrap) | ((c + 1u) & wrap); return bhrt_rand31(key, c); }
     __device__ float rnd01() // MtlBlinn.cpp:42-49
     {
         float r = dm::rand_to_unit(rand());

@@ -365,7 +365,7 @@ constexpr uint32_t kMeshNodelet = 256;
 #endif
 constexpr int kMeshBlock = BHRT_MESH_BLOCK;
 template <bool kCamera, int kPath, bool kLS = false> // kPath: 0 parent links, 1 path in LDS with 16-bit entries, 2 with 32-bit entries; kLS: bhrt_opts::leaf_skip
-__global__ void __launch_bounds__(kCamera ? kBlock : kMeshBlock, 6) k_trace_mesh(DevScene S, PassInfo P, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
+__global__ void __launch_bounds__(kCamera ? kBlock : kMeshBlock, kPath == 1 ? 6 : 4 /* the 32-bit path stack / the nodelet leave room for four */) k_trace_mesh(DevScene S, PassInfo P, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
 {
     typedef typename std::conditional<kPath == 2, uint32_t, uint16_t>::type PathT;
     constexpr int kTB = kCamera ? kBlock : kMeshBlock;
@@ -426,7 +426,7 @@ __device__ unsigned long long g_stream_t[4]; // wall clock (100 MHz): first wave
 __device__ unsigned long long g_stream_dbg[8]; // rounds, lanes with a walk, lanes in the round's phase, clocks in rounds, clocks outside, refills, descend / leaf rounds
 #endif
 template <int kPath, bool kLS = false> // 1: 16-bit path entries, 2: 32-bit (see k_trace_mesh)
-__global__ void __launch_bounds__(64, BHRT_STREAM_OCC) k_trace_mesh_stream(DevScene S, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
+__global__ void __launch_bounds__(64, kPath == 1 ? BHRT_STREAM_OCC : (BHRT_STREAM_OCC < 5 ? BHRT_STREAM_OCC : 5) /* 32-bit path entries: LDS holds five waves per SIMD */) k_trace_mesh_stream(DevScene S, RayQueue q, HitBuf h, RayOrder ord, Counters *cnt)
 {
     typedef typename std::conditional<kPath == 2, uint32_t, uint16_t>::type PathT;
     __shared__ PathT path[33 * 64];
@@ -1406,9 +1406,11 @@ __device__ inline uint32_t cell_add_wave(uint32_t *cells, uint32_t c, bool activ
     if ((todo >> lane) & 1ull) slot = atomicAdd(&cells[c], 1u);
     return slot;
 }
+// The slot cell_add_wave returns in the COUNT pass is the query's rank inside its cell: kept (rank_of), it makes the scatter pass a plain read of
+// the scanned counter instead of a second round of atomics on the 512 MB table (round 3).
 template <class Sink>
 __global__ void __launch_bounds__(kBlock) k_gather_cell_count(Sink sink, uint32_t q0, uint32_t cnt, GatherGrid G, PhotonMapDev M, float radius, uint32_t *cell_of,
-                                                              uint32_t *cell_count)
+                                                              uint32_t *rank_of, uint32_t *cell_count)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t c = BHRT_GATHER_NO_CELL;
@@ -1421,7 +1423,8 @@ __global__ void __launch_bounds__(kBlock) k_gather_cell_count(Sink sink, uint32_
         }
         cell_of[i] = c;
     }
-    cell_add_wave(cell_count, c, c != BHRT_GATHER_NO_CELL);
+    const uint32_t r = cell_add_wave(cell_count, c, c != BHRT_GATHER_NO_CELL);
+    if (i < cnt) rank_of[i] = r;
 }
 // exclusive scan of cell_count[BHRT_GATHER_CELLS] in place, three launches: per-block sums, scan of the sums, add back
 constexpr uint32_t kScanBlock = 1024, kScanPerThread = 8, kScanTile = kScanBlock * kScanPerThread;
@@ -1472,13 +1475,13 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t *data, uint32_
 } // namespace bhrt
 #include "device_photon_build.h"
 namespace bhrt {
-__global__ void __launch_bounds__(kBlock) k_gather_cell_scatter(uint32_t q0, uint32_t cnt, const uint32_t *cell_of, uint32_t *cell_cursor, uint32_t *order)
+__global__ void __launch_bounds__(kBlock) k_gather_cell_scatter(uint32_t q0, uint32_t cnt, const uint32_t *cell_of, const uint32_t *rank_of, const uint32_t *cell_start, uint32_t *order)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t c = i < cnt ? cell_of[i] : BHRT_GATHER_NO_CELL;
-    const uint32_t slot = cell_add_wave(cell_cursor, c, c != BHRT_GATHER_NO_CELL);
-    if (c != BHRT_GATHER_NO_CELL) order[slot] = q0 + i;
+    if (c != BHRT_GATHER_NO_CELL) order[cell_start[c] + rank_of[i]] = q0 + i;
 }
+
 
 // Pass 1: every query walks the map without a candidate list (photon_estimate_fast).  Queries that meet their 1000th
 // photon are appended to `heavy` (pass 3), queries whose walk is longer than the lane budget to `longq` (pass 2).
@@ -1504,24 +1507,29 @@ __device__ inline void count_visited(uint32_t visited, uint32_t *counts)
 }
 template <class Sink>
 __global__ void __launch_bounds__(kBlock) k_photon_gather_fast(Sink sink, uint32_t q0, uint32_t cnt, const uint32_t *order, PhotonMapDev M, float radius,
-                                                               int lane_budget, uint32_t *heavy, uint32_t *longq, uint32_t *counts /* [0] heavy, [1] long, [2..3] visited */)
+                                                               int lane_budget, uint32_t *heavy, uint32_t *longq, uint32_t *counts /* [0] heavy, [1] long, [2..3] visited, [8..9] found, [10..11] answered */)
 {
     uint32_t slice;
     xcd_slice(blockIdx.x, gridDim.x, slice); // cell-sorted order: one contiguous eighth of it per XCD
     const uint32_t i = slice * blockDim.x + threadIdx.x;
-    int r = 0;
+    int r = 0, found = 0;
     uint32_t q = 0, visited = 0;
     if (i < cnt) {
         q = order ? order[i] : q0 + i;
         if (!sink.skip(q)) {
             V3 irr, d;
-            r = photon_estimate_fast(M, sink.pos(q), sink.nrm(q), radius, lane_budget, irr, d, visited);
+            r = photon_estimate_fast(M, sink.pos(q), sink.nrm(q), radius, lane_budget, irr, d, visited, found);
             if (r < 2) sink.done(q, r == 1, irr, d);
         }
     }
     wave_append(r == 2, q, heavy, &counts[0]);
     wave_append(r == 3, q, longq, &counts[1]);
     count_visited(visited, counts);
+    { // photons the queries answered HERE were made of (the floor of the nodes a walk has to examine), and how many queries those were
+        uint32_t f = r < 2 ? (uint32_t)found : 0u, nq = (i < cnt && r < 2) ? 1u : 0u;
+        for (int off = 32; off > 0; off >>= 1) { f += __shfl_xor(f, off); nq += __shfl_xor(nq, off); }
+        if (__lane_id() == 0 && nq) { atomicAdd((unsigned long long *)(counts + 8), (unsigned long long)f); atomicAdd((unsigned long long *)(counts + 10), (unsigned long long)nq); }
+    }
 }
 // Exact replay: the queries of heavy[h0, h0+cnt) with the full candidate heap, one scratch column per lane.
 template <class Sink>
@@ -1680,7 +1688,26 @@ struct DeviceState {
     uint32_t heavy_cap = 0;
     uint32_t *d_n_heavy = nullptr, *h_n_heavy = nullptr; // [0] heavy, [1] long
     uint32_t *d_long = nullptr;  // queries whose walk outlasted the lane budget in pass 1
-    uint32_t *d_cell_of = nullptr, *d_gorder = nullptr; // gather order (cell sort): heavy_cap entries each
+    uint32_t *d_cell_of = nullptr, *d_gorder = nullptr, *d_rank_of = nullptr; // gather order (cell sort): heavy_cap entries each
+    // Development switches, read from the environment ONCE, when the scene is uploaded (none changes a result), and the two test knobs, which
+    // no environment variable reaches: only bhrt_scene_knob sets them.
+    struct Knobs {
+        int stream_waves = -1;          // BHRT_STREAM_WAVES: resident waves of k_trace_mesh_stream; 0 = the launch-per-64-rays kernel; -1 = default
+        bool fused_camera = true;       // BHRT_FUSED_CAMERA=0: two-kernel camera step in mesh-free scenes
+        bool no_slow_queue = false;     // BHRT_NO_SLOW_QUEUE: axis-parallel rays stay in their wave steps
+        bool debug_slow = false, debug_gather = false, debug_drain = false; // BHRT_DEBUG_*: statistics on stderr
+        bool balance_host = false;      // BHRT_PHOTON_BALANCE_HOST: photon_host.cpp instead of k_pb_level (the tests' second opinion)
+        int frame_cap = 0;              // knob "frame_cap": a frame pool that overflows (the retry path under test); 0 = off
+        int gather_lane_budget = 0;     // knob "gather_lane_budget": photons a lane may visit before its query goes to the one-wave pass; 0 = default
+        void FromEnv()
+        {
+            if (const char *e = getenv("BHRT_STREAM_WAVES")) stream_waves = atoi(e);
+            if (const char *e = getenv("BHRT_FUSED_CAMERA")) fused_camera = atoi(e) != 0;
+            no_slow_queue = getenv("BHRT_NO_SLOW_QUEUE") != nullptr;
+            debug_slow = getenv("BHRT_DEBUG_SLOW") != nullptr; debug_gather = getenv("BHRT_DEBUG_GATHER") != nullptr; debug_drain = getenv("BHRT_DEBUG_DRAIN") != nullptr;
+            if (const char *e = getenv("BHRT_PHOTON_BALANCE_HOST")) balance_host = atoi(e) != 0;
+        }
+    } knobs;
     uint32_t *d_cells = nullptr, *d_tile_sums = nullptr;
     // a capacity overflow halves the pass (RenderRange); later frames of the same scene and options start from the reduced size
     uint64_t pass_hint_key = 0;
@@ -1706,7 +1733,7 @@ void DestroyDeviceState(DeviceState *d)
     for (int k = 0; k < 2; k++) { fr(d->d_rayf[k]); fr(d->d_rayu[k]); }
     fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_park); fr(d->d_seg); fr(d->d_cnt); fr(d->d_aux);
     fr(d->d_frame_rgb); fr(d->d_frame_rad); fr(d->d_sel); fr(d->d_slowf); fr(d->d_slowu);
-    fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_ph_dbox); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_cells); fr(d->d_tile_sums);
+    fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_ph_dbox); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_rank_of); fr(d->d_cells); fr(d->d_tile_sums);
     if (d->h_n_heavy) (void)hipHostFree(d->h_n_heavy);
     if (d->h_pub) (void)hipHostFree(d->h_pub);
     for (int k = 0; k < 2; k++) if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
@@ -1896,18 +1923,19 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
     if (cnt == 0) return BHRT_OK;
     if (D->heavy_cap < cnt) {
         auto fr = [](uint32_t *&p) { if (p) (void)hipFree(p); p = nullptr; };
-        fr(D->d_heavy); fr(D->d_long); fr(D->d_cell_of); fr(D->d_gorder);
+        fr(D->d_heavy); fr(D->d_long); fr(D->d_cell_of); fr(D->d_gorder); fr(D->d_rank_of);
         D->heavy_cap = 0;
         HIP_CHECK(hipMalloc(&D->d_heavy, (size_t)cnt * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc(&D->d_long, (size_t)cnt * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc(&D->d_cell_of, (size_t)cnt * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc(&D->d_gorder, (size_t)cnt * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&D->d_rank_of, (size_t)cnt * sizeof(uint32_t)));
         D->heavy_cap = cnt;
     }
     if (!D->d_n_heavy) {
-        HIP_CHECK(hipMalloc(&D->d_n_heavy, 8 * sizeof(uint32_t))); // [0] heavy, [1] long, [2..3] nodes visited (64-bit), [4] selection rounds, [5] compactions
-        HIP_CHECK(hipHostMalloc(&D->h_n_heavy, 8 * sizeof(uint32_t)));
-        HIP_CHECK(hipMalloc(&D->d_cells, (size_t)BHRT_GATHER_CELLS * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&D->d_n_heavy, 12 * sizeof(uint32_t))); // [0] heavy, [1] long, [2..3] nodes visited (64-bit), [4] selection rounds, [5] compactions, [8..11] lane pass: found, answered
+        HIP_CHECK(hipHostMalloc(&D->h_n_heavy, 12 * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&D->d_cells, ((size_t)BHRT_GATHER_CELLS + 1) * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc(&D->d_tile_sums, (size_t)(BHRT_GATHER_CELLS / kScanTile + kScanBlock) * sizeof(uint32_t)));
     }
     dim3 grid((cnt + kBlock - 1) / kBlock);
@@ -1922,32 +1950,35 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
             G.inv_cell[k] = hi > lo ? (float)(1 << BHRT_GATHER_CELL_BITS) / (hi - lo) : 0.f;
         }
         const uint32_t n_tiles = BHRT_GATHER_CELLS / kScanTile;
-        HIP_CHECK(hipMemsetAsync(D->d_cells, 0, (size_t)BHRT_GATHER_CELLS * sizeof(uint32_t), D->stream));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_cell_count<Sink>), grid, block, 0, D->stream, sink, q0, cnt, G, D->pm, radius, D->d_cell_of, D->d_cells);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, D->d_cells, BHRT_GATHER_CELLS, D->d_tile_sums);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, D->stream, D->d_tile_sums, n_tiles);
-        hipLaunchKernelGGL(k_scan_add, dim3(n_tiles), dim3(kScanBlock), 0, D->stream, D->d_cells, BHRT_GATHER_CELLS, D->d_tile_sums);
-        hipLaunchKernelGGL(k_gather_cell_scatter, grid, block, 0, D->stream, q0, cnt, D->d_cell_of, D->d_cells, D->d_gorder);
+        HIP_CHECK(hipMemsetAsync(D->d_cells, 0, ((size_t)BHRT_GATHER_CELLS + 1) * sizeof(uint32_t), D->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_cell_count<Sink>), grid, block, 0, D->stream, sink, q0, cnt, G, D->pm, radius, D->d_cell_of, D->d_rank_of, D->d_cells);
+        // exclusive scan over the cells and one more entry, which ends up holding the number of queries that take part
+        hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles + 1), dim3(kScanBlock), 0, D->stream, D->d_cells, BHRT_GATHER_CELLS + 1, D->d_tile_sums);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, D->stream, D->d_tile_sums, n_tiles + 1);
+        hipLaunchKernelGGL(k_scan_add, dim3(n_tiles + 1), dim3(kScanBlock), 0, D->stream, D->d_cells, BHRT_GATHER_CELLS + 1, D->d_tile_sums);
+        hipLaunchKernelGGL(k_gather_cell_scatter, grid, block, 0, D->stream, q0, cnt, D->d_cell_of, D->d_rank_of, D->d_cells, D->d_gorder);
         order = D->d_gorder;
-        // the last cell's cursor now stands at the end of the order = the number of queries that take part
-        HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_cells + (BHRT_GATHER_CELLS - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
+        HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_cells + BHRT_GATHER_CELLS, sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
         HIP_CHECK(hipStreamSynchronize(D->stream));
         n_walk = D->h_n_heavy[0];
         grid = dim3((n_walk + kBlock - 1) / kBlock);
     }
-    HIP_CHECK(hipMemsetAsync(D->d_n_heavy, 0, 4 * sizeof(uint32_t), D->stream));
+    HIP_CHECK(hipMemsetAsync(D->d_n_heavy, 0, 12 * sizeof(uint32_t), D->stream));
     int lane_budget = BHRT_GATHER_LANE_BUDGET;
-    if (const char *e = getenv("BHRT_GATHER_LANE_BUDGET")) lane_budget = std::max(1, atoi(e)); // test knob: a tiny budget sends every query through pass 2
+    if (D->knobs.gather_lane_budget > 0) lane_budget = D->knobs.gather_lane_budget; // test knob: a tiny budget sends every query through pass 2
     // (Streaming the queries through resident waves, lanes refilled from a cursor as in k_trace_mesh_stream, is SLOWER here — 0.69 -> 0.81-1.01 s per
     // frame for refill thresholds of 60-16 lanes: the 64 queries of a wave come from one cell and walk the tree in step, so their loads hit
     // the same lines; refilled lanes are out of step with their neighbours and every load becomes a gather.  33 of 64 lanes busy is the cheaper evil.)
     if (n_walk > 0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_fast<Sink>), grid, block, 0, D->stream, sink, q0, n_walk, order, D->pm, radius, lane_budget, D->d_heavy,
                            D->d_long, D->d_n_heavy);
-    HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_n_heavy, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
+    HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_n_heavy, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
     HIP_CHECK(hipStreamSynchronize(D->stream));
     const uint32_t n_heavy = D->h_n_heavy[0], n_long = D->h_n_heavy[1];
     if (st) {
+        st->photon_found += (uint64_t)D->h_n_heavy[8] | ((uint64_t)D->h_n_heavy[9] << 32);
+        st->photon_lane_queries += (uint64_t)D->h_n_heavy[10] | ((uint64_t)D->h_n_heavy[11] << 32);
+        st->photon_lane_nodes += (uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32);
         st->photon_queries += cnt;
         st->photon_wave_queries += n_long;
         st->photon_heavy_queries += n_heavy;
@@ -1969,7 +2000,7 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
         HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_n_heavy, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
         HIP_CHECK(hipStreamSynchronize(D->stream));
         if (st) st->photon_nodes_visited += (uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32);
-        if (getenv("BHRT_DEBUG_GATHER"))
+        if (D->knobs.debug_gather)
             fprintf(stderr, "select pass: %u heavy + %u long queries, %llu nodes, %u rounds, %u compactions, %u undecided\n", n_sel_heavy, n_long,
                     (unsigned long long)((uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32)), D->h_n_heavy[4], D->h_n_heavy[5], D->h_n_heavy[0]);
         n_exact = D->h_n_heavy[0];
@@ -2061,7 +2092,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         }
     }
     // resident waves of the streaming mesh kernels (k_trace_mesh_stream): 6 per SIMD; BHRT_STREAM_WAVES=0 selects the launch-per-64-rays kernels
-    const uint32_t stream_waves = getenv("BHRT_STREAM_WAVES") ? (uint32_t)atoi(getenv("BHRT_STREAM_WAVES")) : D->n_cus * 4u * (uint32_t)BHRT_STREAM_OCC;
+    const uint32_t stream_waves = D->knobs.stream_waves >= 0 ? (uint32_t)D->knobs.stream_waves : D->n_cus * 4u * (uint32_t)BHRT_STREAM_OCC;
     RenderParams R;
     R.internal_bounces = o.internal_bounces; R.gi_bounces = o.gi_bounces; R.photon = o.photon_map;
     auto wall0 = std::chrono::steady_clock::now();
@@ -2075,7 +2106,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         int rc = EnsureWorkspace(D, pass_samples, frames_per_sample);
         if (rc) return rc;
         R.cap_rays = D->cap_rays; R.cap_shadow = D->cap_rays; R.cap_frames = D->cap_frames;
-        if (const char *e = getenv("BHRT_TEST_FRAME_CAP")) R.cap_frames = std::min<uint32_t>(R.cap_frames, (uint32_t)std::max(1, atoi(e))); // test knob: a pass that overflows
+        if (D->knobs.frame_cap > 0) R.cap_frames = std::min<uint32_t>(R.cap_frames, (uint32_t)D->knobs.frame_cap); // test knob: a pass that overflows
         if (o.photon_map) {
             if (D->ph_frames_cap < D->cap_frames) {
                 if (D->d_ph_frames) (void)hipFree(D->d_ph_frames);
@@ -2110,7 +2141,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         SlowQueue slowq;
         slowq.q = MakeRayQueue(D->d_slowf, D->d_slowu, kSlowCap);
         slowq.cap = D->d_slowf ? kSlowCap : 0u;
-        if (getenv("BHRT_NO_SLOW_QUEUE")) slowq.cap = 0;
+        if (D->knobs.no_slow_queue) slowq.cap = 0;
         const SlowQueue no_slow = {slowq.q, 0u};
         HitBuf slow_hits; slow_hits.t = D->d_slowf ? D->d_slowf + (size_t)6 * kSlowCap : nullptr; slow_hits.node = (int32_t *)(D->d_slowu ? D->d_slowu + (size_t)3 * kSlowCap : nullptr);
         slow_hits.prim = slow_hits.node ? slow_hits.node + kSlowCap : nullptr; slow_hits.front = slow_hits.node ? slow_hits.node + 2 * (size_t)kSlowCap : nullptr;
@@ -2122,7 +2153,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             if (n_cur == 0) {
                 const auto w0 = std::chrono::steady_clock::now();
                 HIP_CHECK(hipStreamSynchronize(D->stream2)); // the slow rays' hits
-                if (getenv("BHRT_DEBUG_SLOW"))
+                if (D->knobs.debug_slow)
                     fprintf(stderr, "slow rays: %u moved in after wave step %u, waited %.1f ms for their hits, pass time so far %.1f ms\n", slow_pending, pass_steps,
                             std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() * 1e3, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3);
                 n_cur = slow_pending;
@@ -2139,8 +2170,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             }
             const SlowQueue &sq = slowq;
             // the camera step of a scene without meshes: k_shade traces its rays itself (shade_block's kFused); BHRT_FUSED_CAMERA=0: the two-kernel form
-            static const bool fuse_camera = !getenv("BHRT_FUSED_CAMERA") || atoi(getenv("BHRT_FUSED_CAMERA")) != 0;
-            const bool fused = first_step && H->n_meshes == 0 && fuse_camera;
+            const bool fused = first_step && H->n_meshes == 0 && D->knobs.fused_camera;
             if (fused) {
             } else if (injected) {
                 Timer t(D, &st->seconds_trace_closest);
@@ -2178,7 +2208,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                         HIP_CHECK(hipMemcpyFromSymbol(t1, HIP_SYMBOL(g_stream_t), sizeof(t1)));
                         static double dbg_total = 0, dbg_drain = 0;
                         if (t1[1] != ~0ull) { dbg_total += (double)(t1[2] - t1[0]) / 1e5; dbg_drain += (double)(t1[2] - t1[1]) / 1e5; }
-                        if (getenv("BHRT_DEBUG_DRAIN")) fprintf(stderr, "mesh launch: %u rays, %.3f ms, of which %.3f ms after the list ran out (sums %.1f / %.1f ms)\n", n_cur, (double)(t1[2] - t1[0]) / 1e5, t1[1] != ~0ull ? (double)(t1[2] - t1[1]) / 1e5 : 0.0, dbg_total, dbg_drain);
+                        if (D->knobs.debug_drain) fprintf(stderr, "mesh launch: %u rays, %.3f ms, of which %.3f ms after the list ran out (sums %.1f / %.1f ms)\n", n_cur, (double)(t1[2] - t1[0]) / 1e5, t1[1] != ~0ull ? (double)(t1[2] - t1[1]) / 1e5 : 0.0, dbg_total, dbg_drain);
 #endif
                     }
                     else
@@ -2231,7 +2261,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             if (slow_pending > slow_traced) { // the rays this step set aside: traced beside the pass
                 const uint32_t cnt_new = slow_pending - slow_traced;
                 hipLaunchKernelGGL(k_trace_slow, dim3(cnt_new), dim3(64), 0, D->stream2, D->S, slowq, slow_traced, slow_pending, slow_hits);
-                if (getenv("BHRT_DEBUG_SLOW")) fprintf(stderr, "slow rays: %u set aside in wave step %u at %.1f ms\n", cnt_new, pass_steps, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3);
+                if (D->knobs.debug_slow) fprintf(stderr, "slow rays: %u set aside in wave step %u at %.1f ms\n", cnt_new, pass_steps, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3);
                 slow_traced = slow_pending;
             }
             const uint32_t n_sh = hc.n_shadow;
@@ -2277,7 +2307,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             // per pass, most with a few hundred frames — spent 2 s per frame waiting for single lanes
             Timer t(D, &st->seconds_photon_gather, 0);
             const GatherToFrames sink = {F, D->S.materials};
-            int rc = RunGather(D, sink, 0, frame_marks.back(), 0.5f /* MAX_Area, MtlBlinn.cpp:29 */, st);
+            int rc = RunGather(D, sink, 0, frame_marks.back(), o.photon_radius > 0.f ? o.photon_radius : 0.5f /* MAX_Area, MtlBlinn.cpp:29 */, st);
             if (rc) return rc;
             t.Stop();
         }
@@ -2320,6 +2350,20 @@ try {
     return BHRT_OK;
 } catch (...) { return bhrt::AbiException(); }
 
+// Test knobs (tests/): "frame_cap" — a frame pool of that many Shade() frames, so that a pass overflows and is redone in halves; "gather_lane_budget" —
+// photons a lane of the gather's first pass may visit before its query is handed to a whole wave.  0 switches a knob off.  Neither changes a result,
+// and no environment variable sets them: a stray variable in a user's environment cannot send a render through the retry path.
+int bhrt_scene_knob(bhrt_scene *scene, const char *name, int value)
+try {
+    int rc = EnsureUploaded(scene);
+    if (rc) return rc;
+    if (!name || value < 0) { SetError("knob: bad arguments"); return BHRT_ERR_ARG; }
+    if (!strcmp(name, "frame_cap")) scene->dev->knobs.frame_cap = value;
+    else if (!strcmp(name, "gather_lane_budget")) scene->dev->knobs.gather_lane_budget = value;
+    else { SetError(std::string("knob: unknown name ") + name); return BHRT_ERR_ARG; }
+    return BHRT_OK;
+} catch (...) { return bhrt::AbiException(); }
+
 int bhrt_scene_upload(bhrt_scene *scene, int device)
 try {
     if (!scene) { SetError("null scene"); return BHRT_ERR_ARG; }
@@ -2331,6 +2375,7 @@ try {
     if (scene->dev) { DestroyDeviceState(scene->dev); scene->dev = nullptr; }
     HIP_CHECK(hipSetDevice(device));
     DeviceState *D = new DeviceState;
+    D->knobs.FromEnv();
     D->device = device;
     scene->dev = D;
     {
@@ -2812,8 +2857,7 @@ static int EnsureHostPhotons(DeviceState *D)
 // the balance of n + 1 emission-order records in HBM: on the device, or (BHRT_PHOTON_BALANCE_HOST=1: the tests' second opinion) by photon_host.cpp
 static int BalanceRecords(DeviceState *D, const DPhoton *d_in, uint32_t n, DPhoton **d_out)
 {
-    static const bool host = getenv("BHRT_PHOTON_BALANCE_HOST") && atoi(getenv("BHRT_PHOTON_BALANCE_HOST")) != 0;
-    if (!host) return BalanceOnDevice(D, d_in, n, d_out);
+    if (!D->knobs.balance_host) return BalanceOnDevice(D, d_in, n, d_out);
     std::vector<HostPhoton> h((size_t)n + 1);
     HIP_CHECK(hipMemcpy(h.data(), d_in, ((size_t)n + 1) * sizeof(DPhoton), hipMemcpyDeviceToHost));
     memset(&h[0], 0, sizeof(HostPhoton));

@@ -65,8 +65,11 @@ typedef struct bhrt_opts {
     /* tile partition: this process renders tiles t with t % world_size == rank */
     int32_t rank, world_size;
     int32_t tile_size;        /* square tile edge in pixels, default 32 */
-    int32_t samples_per_pass; /* upper bound on camera samples in flight per wavefront pass (~1 KB of device memory each, 1.4 KB with the photon map);
-                                 0 = choose: what the frame needs, at most 2^27 (~138 GB / 186 GB), halved until it fits into 85 % of the free memory */
+    int32_t samples_per_pass; /* upper bound on camera samples in flight per wavefront pass.  Device memory per sample: ~1 KB (1.4 KB with the photon map)
+                                 when six Shade() frames are provided per sample slot.  0 = choose: what the frame needs, at most 2^28 slots, halved until
+                                 the workspace fits into 85 % of the free memory — with six frames per slot that is 2^27 (~138 GB / 186 GB); a frame too
+                                 large for one such pass (config 4: 2.65e8 samples per GPU) provides the frames per slot its earlier passes needed + 30 %
+                                 instead (1.7 for config 4: 2^28 slots in 180 GB) and is one pass from its second render on */
     int32_t timers;           /* HIP-event kernel timers of bhrt_stats: 0 = seconds_shade only (default; an event between two kernels
                                * idles the GPU ~6 us), 1 = all kernel groups, -1 = none */
     int32_t photon_exact;     /* caustic gather of queries with >= 1000 photons inside the radius: 0 (default) = the same photon SET as
@@ -75,7 +78,10 @@ typedef struct bhrt_opts {
     int32_t leaf_skip;        /* 1 = the mesh walks leave out a box-missed LEAF sibling (TriObj.cpp:245-248,263-266,286-300) when its visit provably
                                * accepts nothing (bhrt_flat.h: bhrt_mesh::skip_*; proof in scene_host.cpp::ComputeLeafSkip).  Same hit records either
                                * way; 0 (default): on the scenes measured the test costs more instructions than the visits it saves */
-    int32_t reserved[2];
+    float photon_radius;      /* gather radius of the caustic term, MAX_Area (MtlBlinn.cpp:29); 0 = the reference's 0.5.  The photon count of an estimate,
+                               * MAX_PhotonCountInArea = 1000 (MtlBlinn.cpp:28), is a TEMPLATE argument in the reference too (EstimateIrradiance<1000>,
+                               * MtlBlinn.cpp:333) and sizes the candidate lists of the kernels: compile-time here as there (device_photon.h: BHRT_PHOTON_K) */
+    int32_t reserved[1];
 } bhrt_opts;
 
 typedef struct bhrt_stats {
@@ -97,7 +103,9 @@ typedef struct bhrt_stats {
     uint64_t photon_nodes_visited; /* kd-tree nodes whose photon was examined (24 B each: SURVEY.md 8d) */
     uint64_t deferred_rays;        /* rays parallel to a coordinate axis of the mesh they enter (Box.cpp:13-28 ignores that axis: a walk of
                                     * nearly the whole BVH): traced in wave steps of their own at the end of their pass */
-    double reserved[4];
+    /* the lane pass of the gather (k_photon_gather_fast) alone: queries it answered, kd nodes it examined, photons those answers were made of */
+    uint64_t photon_lane_queries, photon_lane_nodes, photon_found;
+    double reserved[1];
 } bhrt_stats;
 
 /* compact hit record written by the trace kernel (SoA on the device: one array per field) */
@@ -133,6 +141,10 @@ int bhrt_scene_flat(const bhrt_scene *scene, const void **blob, uint64_t *bytes)
 
 /* ---- device residency ---------------------------------------------------------------------------- */
 int bhrt_scene_upload(bhrt_scene *scene, int device); /* copies the flat scene into HBM of `device`; idempotent */
+/* test knobs of an uploaded scene ("frame_cap", "gather_lane_budget"; 0 = off): they steer which internal path a render takes, never its result.
+ * The library reads its development switches (BHRT_STREAM_WAVES, BHRT_FUSED_CAMERA, BHRT_NO_SLOW_QUEUE, BHRT_DEBUG_*, BHRT_PHOTON_BALANCE_HOST) from the
+ * environment once, at upload; these two are not reachable from the environment at all. */
+int bhrt_scene_knob(bhrt_scene *scene, const char *name, int value);
 int bhrt_device_count(int *n);
 
 /* ---- the hot path --------------------------------------------------------------------------------- */

@@ -73,7 +73,10 @@ static inline BHRT_HD uint32_t bhrt_photon_key(uint32_t seed, uint64_t emission)
 /* Keyed photon stream of a 64-bit emission index: (key, first counter).  A 32-bit key alone gives 2^32 streams, and the ~2e7
  * emissions of a 1 M-photon caustic map would then contain ~5e4 pairs that replay an identical path (birthday bound).  Emissions
  * [65536 m, 65536 m + 65536) therefore share key(m) and take disjoint 2^16-draw windows of its counter: a 1 M-photon build uses a
- * few hundred keys (collision probability ~1e-5), and two emissions never read the same (key, counter) pair. */
+ * few hundred keys (collision probability ~1e-5), and two emissions never read the same (key, counter) pair: the counter of an emission
+ * advances in its low 16 bits only (BHRT_PHOTON_WINDOW_MASK; kernels and oracle alike), so a path that draws more than 2^16 numbers — a
+ * degenerate hit whose rejection loop runs to its cap — starts over in its own window instead of entering its successors'. */
+#define BHRT_PHOTON_WINDOW_MASK 0xFFFFu
 static inline BHRT_HD void bhrt_photon_stream(uint32_t seed, uint64_t emission, uint32_t *key, uint32_t *counter)
 {
     *key = bhrt_photon_key(seed, emission >> 16);

@@ -208,7 +208,8 @@ struct Rng {
         key = bhrt_section_key(sample_key, path_code, section);
         ctr = 0;
     }
-    int Rand() { return bhrt_rand31(key, ctr++); }
+    uint32_t wrap = 0xffffffffu; // the counter bits that advance (include/bhrt_rng.h: the low 16 for a keyed photon emission)
+    int Rand() { const uint32_t c = ctr; ctr = (c & ~wrap) | ((c + 1u) & wrap); return bhrt_rand31(key, c); }
     bool device_math = false; // device-math mode converts with one multiplication (bhrt_detmath.h::rand_to_unit)
     float ToUnit(int r) const { return device_math ? bhrt::dm::rand_to_unit(r) : (float)((double)r / (BHRT_RAND_MAX)); }
     float Rnd01() // MtlBlinn.cpp:42-49
@@ -1743,7 +1744,7 @@ template <class M> struct PhotonTracer {
         rng.key = bhrt_photon_key_sequential(seed);
         rng.ctr = 0;
         while (pm.numStored < maxPhotons) {
-            if (keyed) bhrt_photon_stream(seed, emitted, &rng.key, &rng.ctr);
+            if (keyed) { bhrt_photon_stream(seed, emitted, &rng.key, &rng.ctr); rng.wrap = BHRT_PHOTON_WINDOW_MASK; }
             float rnd = rng.Rnd01();
             size_t i = 0;
             while (rnd > Color(pl[i]->intensity[0], pl[i]->intensity[1], pl[i]->intensity[2]).Gray() * pl[i]->size / sum && i < pl.size() - 1) i++;

@@ -423,8 +423,10 @@ def test_a_pass_that_overflows_its_frame_pool_is_cut_in_half_and_redone(gpu, loa
     base_rgb, base_rad, st = sc.render(opts)
     assert st.passes == 1
     frames_needed = st.shade_calls if hasattr(st, "shade_calls") else st.camera_samples * 2
-    monkeypatch.setenv("BHRT_TEST_FRAME_CAP", str(max(1, int(frames_needed) // 3)))  # a third of what the one-pass frame needs
+    monkeypatch.setenv("BHRT_TEST_FRAME_CAP", "1")  # no environment variable reaches the knob (a stray one must not send a user's render through retries)
+    sc.knob("frame_cap", max(1, int(frames_needed) // 3))  # a third of what the one-pass frame needs
     rgb, rad, st2 = sc.render(opts)
+    sc.knob("frame_cap", 0)
     monkeypatch.delenv("BHRT_TEST_FRAME_CAP")
     assert st2.passes >= 3
     assert np.array_equal(rgb, base_rgb) and same_bits(rad, base_rad)

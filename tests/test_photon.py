@@ -141,11 +141,8 @@ def test_gpu_photon_map_vs_oracle(B, load_scene, O):
     rn /= np.linalg.norm(rn, axis=1, keepdims=True)
     for radius in (0.5, 1.1):
         oi, od = O.photon_gather(p, rn, radius)
-        for budget in ("1000000000", "1", None):
-            if budget is None:
-                os.environ.pop("BHRT_GATHER_LANE_BUDGET", None)
-            else:
-                os.environ["BHRT_GATHER_LANE_BUDGET"] = budget
+        for budget in (1000000000, 1, 0):  # lane walk only / every query by a whole wave / the default mix (knob off)
+            sc.knob("gather_lane_budget", budget)
             gi, gd = sc.photon_gather(p, rn, radius, exact=True)
             assert same_bits(gi, oi) and same_bits(gd, od), (radius, budget)
             check_selected_photons(sc, O, p, rn, radius)
