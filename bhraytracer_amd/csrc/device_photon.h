@@ -267,14 +267,17 @@ __device__ inline void photon_finish(V3 sumI, V3 sumD, float d2max, V3 &irrad, V
 // met: the caller redoes this query with photon_estimate_heap (the sums then run in heap-array order); 3 = more than
 // `budget` photons visited without an answer: the caller hands the query to a whole wave (k_photon_gather_select), so
 // that one lane's long walk (a dense cluster inside the radius, most of it rejected) does not hold up its launch.
-// found: the photons accepted so far (inside the radius, on the right side) — what the estimate is made of; bhrt_stats.photon_found
-__device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 normal, float radius, int budget, V3 &irrad, V3 &direction, uint32_t &visited, int &found)
+// found_out (statistics instantiation only, knob "gather_stats": the extra live value costs the default kernel 7 % — measured): the photons accepted
+// (inside the radius, on the right side) — what the estimate is made of; bhrt_stats.photon_found
+template <bool kFound = false>
+__device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 normal, float radius, int budget, V3 &irrad, V3 &direction, uint32_t &visited, int *found_out = nullptr)
 {
     irrad = v3(0, 0, 0);
     direction = v3(0, 0, 0);
-    found = 0;
+    if (kFound) *found_out = 0;
     if (M.n <= 0 || photon_outside_bounds(M, pos, radius)) return 0;
     const float d2max = radius * radius;
+    int found = 0;
     V3 sumI = v3(0, 0, 0), sumD = v3(0, 0, 0);
     PhotonWalk w;
     int node;
@@ -295,6 +298,7 @@ __device__ inline int photon_estimate_fast(const PhotonMapDev &M, V3 pos, V3 nor
             }
         }
     }
+    if (kFound) *found_out = found;
     if (found == 0) return 0;
     photon_finish(sumI, sumD, d2max, irrad, direction);
     return 1;

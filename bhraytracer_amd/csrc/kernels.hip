@@ -1505,7 +1505,7 @@ __device__ inline void count_visited(uint32_t visited, uint32_t *counts)
     for (int off = 32; off > 0; off >>= 1) visited += __shfl_xor(visited, off);
     if (__lane_id() == 0 && visited) atomicAdd((unsigned long long *)(counts + 2), (unsigned long long)visited);
 }
-template <class Sink>
+template <class Sink, bool kFound = false> // kFound: the statistics instantiation (knob "gather_stats")
 __global__ void __launch_bounds__(kBlock) k_photon_gather_fast(Sink sink, uint32_t q0, uint32_t cnt, const uint32_t *order, PhotonMapDev M, float radius,
                                                                int lane_budget, uint32_t *heavy, uint32_t *longq, uint32_t *counts /* [0] heavy, [1] long, [2..3] visited, [8..9] found, [10..11] answered */)
 {
@@ -1518,14 +1518,14 @@ __global__ void __launch_bounds__(kBlock) k_photon_gather_fast(Sink sink, uint32
         q = order ? order[i] : q0 + i;
         if (!sink.skip(q)) {
             V3 irr, d;
-            r = photon_estimate_fast(M, sink.pos(q), sink.nrm(q), radius, lane_budget, irr, d, visited, found);
+            r = photon_estimate_fast<kFound>(M, sink.pos(q), sink.nrm(q), radius, lane_budget, irr, d, visited, kFound ? &found : nullptr);
             if (r < 2) sink.done(q, r == 1, irr, d);
         }
     }
     wave_append(r == 2, q, heavy, &counts[0]);
     wave_append(r == 3, q, longq, &counts[1]);
     count_visited(visited, counts);
-    { // photons the queries answered HERE were made of (the floor of the nodes a walk has to examine), and how many queries those were
+    if (kFound) { // photons the queries answered HERE were made of (the floor of the nodes a walk has to examine), and how many queries those were
         uint32_t f = r < 2 ? (uint32_t)found : 0u, nq = (i < cnt && r < 2) ? 1u : 0u;
         for (int off = 32; off > 0; off >>= 1) { f += __shfl_xor(f, off); nq += __shfl_xor(nq, off); }
         if (__lane_id() == 0 && nq) { atomicAdd((unsigned long long *)(counts + 8), (unsigned long long)f); atomicAdd((unsigned long long *)(counts + 10), (unsigned long long)nq); }
@@ -1699,6 +1699,7 @@ struct DeviceState {
         bool balance_host = false;      // BHRT_PHOTON_BALANCE_HOST: photon_host.cpp instead of k_pb_level (the tests' second opinion)
         int frame_cap = 0;              // knob "frame_cap": a frame pool that overflows (the retry path under test); 0 = off
         int gather_lane_budget = 0;     // knob "gather_lane_budget": photons a lane may visit before its query goes to the one-wave pass; 0 = default
+        int gather_stats = 0;           // knob "gather_stats": the lane pass counts the photons its answers are made of (bhrt_stats.photon_found), 7 % slower
         void FromEnv()
         {
             if (const char *e = getenv("BHRT_STREAM_WAVES")) stream_waves = atoi(e);
@@ -1969,15 +1970,20 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
     // (Streaming the queries through resident waves, lanes refilled from a cursor as in k_trace_mesh_stream, is SLOWER here — 0.69 -> 0.81-1.01 s per
     // frame for refill thresholds of 60-16 lanes: the 64 queries of a wave come from one cell and walk the tree in step, so their loads hit
     // the same lines; refilled lanes are out of step with their neighbours and every load becomes a gather.  33 of 64 lanes busy is the cheaper evil.)
-    if (n_walk > 0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_fast<Sink>), grid, block, 0, D->stream, sink, q0, n_walk, order, D->pm, radius, lane_budget, D->d_heavy,
-                           D->d_long, D->d_n_heavy);
+    if (n_walk > 0) {
+        if (D->knobs.gather_stats)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_fast<Sink, true>), grid, block, 0, D->stream, sink, q0, n_walk, order, D->pm, radius, lane_budget, D->d_heavy,
+                               D->d_long, D->d_n_heavy);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_gather_fast<Sink>), grid, block, 0, D->stream, sink, q0, n_walk, order, D->pm, radius, lane_budget, D->d_heavy,
+                               D->d_long, D->d_n_heavy);
+    }
     HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_n_heavy, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
     HIP_CHECK(hipStreamSynchronize(D->stream));
     const uint32_t n_heavy = D->h_n_heavy[0], n_long = D->h_n_heavy[1];
     if (st) {
-        st->photon_found += (uint64_t)D->h_n_heavy[8] | ((uint64_t)D->h_n_heavy[9] << 32);
-        st->photon_lane_queries += (uint64_t)D->h_n_heavy[10] | ((uint64_t)D->h_n_heavy[11] << 32);
+        st->photon_found += (uint64_t)D->h_n_heavy[8] | ((uint64_t)D->h_n_heavy[9] << 32); // knob "gather_stats" only
+        st->photon_lane_queries += (uint64_t)n_walk - n_heavy - n_long;
         st->photon_lane_nodes += (uint64_t)D->h_n_heavy[2] | ((uint64_t)D->h_n_heavy[3] << 32);
         st->photon_queries += cnt;
         st->photon_wave_queries += n_long;
@@ -2360,6 +2366,7 @@ try {
     if (!name || value < 0) { SetError("knob: bad arguments"); return BHRT_ERR_ARG; }
     if (!strcmp(name, "frame_cap")) scene->dev->knobs.frame_cap = value;
     else if (!strcmp(name, "gather_lane_budget")) scene->dev->knobs.gather_lane_budget = value;
+    else if (!strcmp(name, "gather_stats")) scene->dev->knobs.gather_stats = value;
     else { SetError(std::string("knob: unknown name ") + name); return BHRT_ERR_ARG; }
     return BHRT_OK;
 } catch (...) { return bhrt::AbiException(); }

@@ -103,7 +103,8 @@ typedef struct bhrt_stats {
     uint64_t photon_nodes_visited; /* kd-tree nodes whose photon was examined (24 B each: SURVEY.md 8d) */
     uint64_t deferred_rays;        /* rays parallel to a coordinate axis of the mesh they enter (Box.cpp:13-28 ignores that axis: a walk of
                                     * nearly the whole BVH): traced in wave steps of their own at the end of their pass */
-    /* the lane pass of the gather (k_photon_gather_fast) alone: queries it answered, kd nodes it examined, photons those answers were made of */
+    /* the lane pass of the gather (k_photon_gather_fast) alone: queries it answered, kd nodes it examined, and — only with the knob "gather_stats"
+     * (bhrt_scene_knob: a statistics instantiation of the kernel, 7 % slower) — the photons those answers were made of */
     uint64_t photon_lane_queries, photon_lane_nodes, photon_found;
     double reserved[1];
 } bhrt_stats;
