@@ -378,10 +378,7 @@ __device__ inline MeshRef mesh_ref(const DevScene &S, int mi)
 #ifndef BHRT_SKIP_MISSED
 #define BHRT_SKIP_MISSED 1
 #endif
-#ifndef BHRT_EXP_SKIP_LEAVES
-#define BHRT_EXP_SKIP_LEAVES 0 /* measurement only (unsound): box-missed LEAF siblings are left out as well */
-#endif
-__device__ inline bool skip_missed(const MeshRef &M, bool box_hit, uint32_t data) { return BHRT_SKIP_MISSED && M.nested && !box_hit && (BHRT_EXP_SKIP_LEAVES || !(data & 0x80000000u)); }
+__device__ inline bool skip_missed(const MeshRef &M, bool box_hit, uint32_t data) { return BHRT_SKIP_MISSED && M.nested && !box_hit && !(data & 0x80000000u); }
 // A box-missed LEAF sibling (36 % of the closed room's leaf visits, never a hit in 10^9 of them) is visited by the reference all the same, and its
 // triangles are tested without a box test: nothing in IntersectTriangle (TriObj.cpp:68-189) knows the box, and from far away the test's three
 // signed areas are rounding noise.  The visit may be left out when it PROVABLY accepts nothing (the proof, and what the host computes per
