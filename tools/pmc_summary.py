@@ -111,6 +111,8 @@ def main():
         try:
             bj2 = json.load(open(os.path.join(dst, f"{wl}_bench_under_rocprof.json")))
             frames = bj2["steps"] + bj2["warmup"] + 1  # + the untimed first frame
+            if wl == "c5":
+                frames += 1  # + bench.py's untimed statistics frame (knob "gather_stats"): its lane pass is the kernel's second instantiation, same short name
         except Exception:
             pass
         ktime = collections.defaultdict(float)

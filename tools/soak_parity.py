@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Whole-frame parity soak (needs a GPU; the oracle is the checker): every sample of full-size frames of the bench scenes, several seeds,
 HIP path against the oracle's keyed-RNG run, bit for bit.  ~100 s on a GPU box for 3.3e8 samples / 1.9e9 rays.
-Usage: python tools/soak_parity.py [caustics]     (caustics: BASELINE config 5 instead — 1 M photons, whole frame, ~1 min)"""
+Usage: python tools/soak_parity.py [caustics] [leaf_skip]     (caustics: BASELINE config 5 instead — 1 M photons, whole frame, ~1 min;
+leaf_skip: the mesh scenes with bhrt_opts.leaf_skip = 1)"""
 import sys, os, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import bhraytracer_amd as B, oracle_lib as O
@@ -28,7 +29,9 @@ for name, spp, seeds in (("c3_room", 16, (1, 2, 3, 4)), ("c3_mesh", 16, (1, 2)),
     sc = B.Scene(os.path.join("tests/scenes", name + ".xml")); blob = sc.flat_bytes()
     for seed in seeds:
         t0 = time.time()
-        gs, st = sc.render_samples(B.default_opts(spp=spp, gi_bounces=3, seed=seed), 0, 0, sc.width, sc.height)
+        o = B.default_opts(spp=spp, gi_bounces=3, seed=seed)
+        o.leaf_skip = 1 if "leaf_skip" in sys.argv[1:] else 0
+        gs, st = sc.render_samples(o, 0, 0, sc.width, sc.height)
         ro = O.render(blob, sc.width, sc.height, spp, gi=3, seed=seed, region=(0, 0, sc.width, sc.height), threads=16)["samples"]
         same = (gs.view(np.uint32) == ro.view(np.uint32)) | (np.isnan(gs) & np.isnan(ro))
         nb = int((~same).sum())
