@@ -2,7 +2,7 @@
 """Randomised GPU-vs-oracle parity: seeded random scenes (spheres, planes, instances of tests/scenes/mesh_small.obj, nested
 transformed groups, Blinn materials with and without refraction / absorption / checker textures, ambient + direct + point
 lights with and without size), small images, per-sample radiance and hits compared bit for bit.
-Usage: python tools/fuzz_parity.py [n_scenes] [first_seed]        (needs a GPU; the oracle is the checker)"""
+Usage: python tools/fuzz_parity.py [n_scenes] [first_seed] [leaf_skip]        (needs a GPU; the oracle is the checker; leaf_skip: bhrt_opts.leaf_skip = 1)"""
 import os, shutil, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,7 +56,9 @@ def check(seed, B, O, tmp):
         h, r = sc.trace_closest(o, d, side), O.trace_closest(blob, o, d, side)
         ok &= np.array_equal(h["node"], r["node"]) and np.array_equal(h["prim"], r["prim"]) and np.array_equal(h["t"].view(np.uint32), r["t"].view(np.uint32))
     spp, gi = 2, int(rng.integers(0, 4))
-    gs, _ = sc.render_samples(B.default_opts(spp=spp, gi_bounces=gi, seed=seed), 0, 0, sc.width, sc.height)
+    opts = B.default_opts(spp=spp, gi_bounces=gi, seed=seed)
+    opts.leaf_skip = 1 if "leaf_skip" in sys.argv[1:] else 0
+    gs, _ = sc.render_samples(opts, 0, 0, sc.width, sc.height)
     ro = O.render(blob, sc.width, sc.height, spp, gi=gi, seed=seed, region=(0, 0, sc.width, sc.height))["samples"]
     same = (gs.view(np.uint32) == ro.view(np.uint32)) | (np.isnan(gs) & np.isnan(ro))
     ok &= bool(same.all())
