@@ -140,3 +140,30 @@ def test_the_rccl_calls_of_the_exchange_in_a_world_of_one(tmp_path):
     code = _RCCL_WORLD_OF_ONE.format(root=ROOT, port=29700 + os.getpid() % 1000, scene=os.path.join(SCENES, "c2_glass_small.xml"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl world of one: ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_bench_line_of_the_default_run_carries_what_the_contract_asks_for():
+    """`python bench.py` as the driver runs it (fewer steps here): ONE JSON line whose headline is BASELINE config 3 with `roofline` (incl. the
+    lane-slot figures the PMC passes gave) and `cpu_baseline` (the reference where oracle/_ref travelled, else the port), the other configurations
+    under `configs`, the D2H / PNG lines, exit code 0."""
+    import json, subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--config-steps", "1", "--config-warmup", "0", "--cpu-sample-spp", "2"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f32" and d["vs_baseline"] is None and d["unit"] == "Mrays/s"
+    assert "c3_mesh.xml 1920x1080, 64 spp" in d["config"]["workload"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1
+    assert rf["traffic"] and 0 < rf["valu_lane_frac"] < 1 and rf["valu_lanes_per_inst"] <= 64
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and "2 of the workload's 64 samples per pixel" in cb["sample"]
+    assert set(d["configs"]) == {"c2", "c3room", "c4", "c5"} and all("error" not in v and v["ms_per_step"] > 0 for v in d["configs"].values())
+    assert d["configs"]["c5"]["photon"]["build_s"] < 0.5 and d["configs"]["c5"]["photon"]["lane_pass_found_per_query"] > 1
+    assert d["wall_clock_extra"]["d2h_ms"] > 0 and d["wall_clock_extra"]["png_encode_ms"] > 0
