@@ -3167,7 +3167,16 @@ try {
     fclose(fp);
     if (!ok) { D->h_photons.clear(); SetError("photon file: short read"); return BHRT_ERR_IO; }
     memset(&D->h_photons[0], 0, sizeof(HostPhoton));
-    if (rebalance) BalancePhotons(D->h_photons); // InitializePhotonMapByFile runs PrepareForIrradianceEstimation again (cyPhotonMap.h:409-417)
+    if (rebalance) { // InitializePhotonMapByFile runs PrepareForIrradianceEstimation again (cyPhotonMap.h:409-417): on the device like the build's
+        DPhoton *d = nullptr, *bal = nullptr;
+        HIP_CHECK(hipMalloc(&d, (n + 1) * sizeof(DPhoton)));
+        hipError_t e = hipMemcpy(d, D->h_photons.data(), (n + 1) * sizeof(DPhoton), hipMemcpyHostToDevice);
+        if (e == hipSuccess) rc = BalanceRecords(D, d, (uint32_t)n, &bal);
+        (void)hipFree(d);
+        HIP_CHECK(e);
+        if (rc) return rc;
+        return InstallPhotonMapDev(D, bal, (uint32_t)n); // the host copy is fetched again when somebody asks for it
+    }
     return InstallPhotonMap(D);
 } catch (...) { return bhrt::AbiException(); }
 
