@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libbhrt.so")
 CLI = os.path.join(HERE, "bhrt")
 
 HOST_SRCS = ["scene_host.cpp", "png_io.cpp", "capi_host.cpp", "photon_host.cpp"]
-HIP_SRCS = ["kernels.hip", "bvh_build.hip"]
+HIP_SRCS = ["kernels.hip", "bvh_build.hip", "gather_sort.hip"]
 COMMON = ["-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

@@ -1481,6 +1481,32 @@ __global__ void __launch_bounds__(kBlock) k_gather_cell_scatter(uint32_t q0, uin
     const uint32_t c = i < cnt ? cell_of[i] : BHRT_GATHER_NO_CELL;
     if (c != BHRT_GATHER_NO_CELL) order[cell_start[c] + rank_of[i]] = q0 + i;
 }
+// The same order from a radix sort of (cell, query) pairs (gather_sort.hip): the key of a query that takes no part is one bit above every cell, so
+// those sort to the end; the number that do take part = the position of the first such key (k_gather_first_out: one lane, a binary search).
+#define BHRT_GATHER_KEY_OUT BHRT_GATHER_CELLS
+template <class Sink>
+__global__ void __launch_bounds__(kBlock) k_gather_cell_key(Sink sink, uint32_t q0, uint32_t cnt, GatherGrid G, PhotonMapDev M, float radius, uint32_t *keys, uint32_t *vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const uint32_t q = q0 + i;
+    uint32_t c = BHRT_GATHER_KEY_OUT;
+    if (!sink.skip(q)) {
+        const V3 p = sink.pos(q);
+        if (photon_outside_bounds(M, p, radius)) sink.done(q, false, v3(0, 0, 0), v3(0, 0, 0)); // photon_estimate_fast's own first test: no photon, zero estimate
+        else c = gather_cell(G, p);
+    }
+    keys[i] = c;
+    vals[i] = q;
+}
+__global__ void k_gather_first_out(const uint32_t *sorted_keys, uint32_t cnt, uint32_t *out)
+{
+    uint32_t lo = 0, hi = cnt; // first index whose key is >= BHRT_GATHER_KEY_OUT
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (sorted_keys[mid] < BHRT_GATHER_KEY_OUT) lo = mid + 1; else hi = mid; }
+    *out = lo;
+}
+int GatherSortPairs(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, void *temp, size_t *temp_bytes, int end_bit,
+                    hipStream_t stream); // gather_sort.hip
 
 
 // Pass 1: every query walks the map without a candidate list (photon_estimate_fast).  Queries that meet their 1000th
@@ -1688,7 +1714,9 @@ struct DeviceState {
     uint32_t heavy_cap = 0;
     uint32_t *d_n_heavy = nullptr, *h_n_heavy = nullptr; // [0] heavy, [1] long
     uint32_t *d_long = nullptr;  // queries whose walk outlasted the lane budget in pass 1
-    uint32_t *d_cell_of = nullptr, *d_gorder = nullptr, *d_rank_of = nullptr; // gather order (cell sort): heavy_cap entries each
+    uint32_t *d_cell_of = nullptr, *d_gorder = nullptr, *d_rank_of = nullptr, *d_keys_out = nullptr; // gather order (cell sort): heavy_cap entries each
+    void *d_sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
     // Development switches, read from the environment ONCE, when the scene is uploaded (none changes a result), and the two test knobs, which
     // no environment variable reaches: only bhrt_scene_knob sets them.
     struct Knobs {
@@ -1699,6 +1727,7 @@ struct DeviceState {
         bool balance_host = false;      // BHRT_PHOTON_BALANCE_HOST: photon_host.cpp instead of k_pb_level (the tests' second opinion)
         int frame_cap = 0;              // knob "frame_cap": a frame pool that overflows (the retry path under test); 0 = off
         int gather_lane_budget = 0;     // knob "gather_lane_budget": photons a lane may visit before its query goes to the one-wave pass; 0 = default
+        bool gather_counting_sort = false; // BHRT_GATHER_COUNTING_SORT=1: the cell order by the counting sort instead of the radix sort of pairs
         int gather_stats = 0;           // knob "gather_stats": the lane pass counts the photons its answers are made of (bhrt_stats.photon_found), 7 % slower
         void FromEnv()
         {
@@ -1707,6 +1736,7 @@ struct DeviceState {
             no_slow_queue = getenv("BHRT_NO_SLOW_QUEUE") != nullptr;
             debug_slow = getenv("BHRT_DEBUG_SLOW") != nullptr; debug_gather = getenv("BHRT_DEBUG_GATHER") != nullptr; debug_drain = getenv("BHRT_DEBUG_DRAIN") != nullptr;
             if (const char *e = getenv("BHRT_PHOTON_BALANCE_HOST")) balance_host = atoi(e) != 0;
+            if (const char *e = getenv("BHRT_GATHER_COUNTING_SORT")) gather_counting_sort = atoi(e) != 0;
         }
     } knobs;
     uint32_t *d_cells = nullptr, *d_tile_sums = nullptr;
@@ -1734,7 +1764,7 @@ void DestroyDeviceState(DeviceState *d)
     for (int k = 0; k < 2; k++) { fr(d->d_rayf[k]); fr(d->d_rayu[k]); }
     fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_park); fr(d->d_seg); fr(d->d_cnt); fr(d->d_aux);
     fr(d->d_frame_rgb); fr(d->d_frame_rad); fr(d->d_sel); fr(d->d_slowf); fr(d->d_slowu);
-    fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_ph_dbox); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_rank_of); fr(d->d_cells); fr(d->d_tile_sums);
+    fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_ph_dbox); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_rank_of); fr(d->d_keys_out); if (d->d_sort_temp) (void)hipFree(d->d_sort_temp); fr(d->d_cells); fr(d->d_tile_sums);
     if (d->h_n_heavy) (void)hipHostFree(d->h_n_heavy);
     if (d->h_pub) (void)hipHostFree(d->h_pub);
     for (int k = 0; k < 2; k++) if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
@@ -1924,13 +1954,18 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
     if (cnt == 0) return BHRT_OK;
     if (D->heavy_cap < cnt) {
         auto fr = [](uint32_t *&p) { if (p) (void)hipFree(p); p = nullptr; };
-        fr(D->d_heavy); fr(D->d_long); fr(D->d_cell_of); fr(D->d_gorder); fr(D->d_rank_of);
+        fr(D->d_heavy); fr(D->d_long); fr(D->d_cell_of); fr(D->d_gorder); fr(D->d_rank_of); fr(D->d_keys_out);
+        if (D->d_sort_temp) (void)hipFree(D->d_sort_temp);
+        D->d_sort_temp = nullptr; D->sort_temp_bytes = 0;
         D->heavy_cap = 0;
         HIP_CHECK(hipMalloc(&D->d_heavy, (size_t)cnt * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc(&D->d_long, (size_t)cnt * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc(&D->d_cell_of, (size_t)cnt * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc(&D->d_gorder, (size_t)cnt * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc(&D->d_rank_of, (size_t)cnt * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&D->d_keys_out, (size_t)cnt * sizeof(uint32_t)));
+        if (GatherSortPairs(nullptr, nullptr, nullptr, nullptr, cnt, nullptr, &D->sort_temp_bytes, 28, D->stream) != 0) { SetError("gather sort: temp size"); return BHRT_ERR_HIP; }
+        HIP_CHECK(hipMalloc(&D->d_sort_temp, std::max<size_t>(D->sort_temp_bytes, 16)));
         D->heavy_cap = cnt;
     }
     if (!D->d_n_heavy) {
@@ -1950,16 +1985,24 @@ static int RunGather(DeviceState *D, const Sink &sink, uint32_t q0, uint32_t cnt
             G.lo[k] = lo;
             G.inv_cell[k] = hi > lo ? (float)(1 << BHRT_GATHER_CELL_BITS) / (hi - lo) : 0.f;
         }
-        const uint32_t n_tiles = BHRT_GATHER_CELLS / kScanTile;
-        HIP_CHECK(hipMemsetAsync(D->d_cells, 0, ((size_t)BHRT_GATHER_CELLS + 1) * sizeof(uint32_t), D->stream));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_cell_count<Sink>), grid, block, 0, D->stream, sink, q0, cnt, G, D->pm, radius, D->d_cell_of, D->d_rank_of, D->d_cells);
-        // exclusive scan over the cells and one more entry, which ends up holding the number of queries that take part
-        hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles + 1), dim3(kScanBlock), 0, D->stream, D->d_cells, BHRT_GATHER_CELLS + 1, D->d_tile_sums);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, D->stream, D->d_tile_sums, n_tiles + 1);
-        hipLaunchKernelGGL(k_scan_add, dim3(n_tiles + 1), dim3(kScanBlock), 0, D->stream, D->d_cells, BHRT_GATHER_CELLS + 1, D->d_tile_sums);
-        hipLaunchKernelGGL(k_gather_cell_scatter, grid, block, 0, D->stream, q0, cnt, D->d_cell_of, D->d_rank_of, D->d_cells, D->d_gorder);
+        if (D->knobs.gather_counting_sort) { // the counting sort of rounds 1-3 (BHRT_GATHER_COUNTING_SORT=1: A/B and second opinion)
+            const uint32_t n_tiles = BHRT_GATHER_CELLS / kScanTile;
+            HIP_CHECK(hipMemsetAsync(D->d_cells, 0, ((size_t)BHRT_GATHER_CELLS + 1) * sizeof(uint32_t), D->stream));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_cell_count<Sink>), grid, block, 0, D->stream, sink, q0, cnt, G, D->pm, radius, D->d_cell_of, D->d_rank_of, D->d_cells);
+            // exclusive scan over the cells and one more entry, which ends up holding the number of queries that take part
+            hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles + 1), dim3(kScanBlock), 0, D->stream, D->d_cells, BHRT_GATHER_CELLS + 1, D->d_tile_sums);
+            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, D->stream, D->d_tile_sums, n_tiles + 1);
+            hipLaunchKernelGGL(k_scan_add, dim3(n_tiles + 1), dim3(kScanBlock), 0, D->stream, D->d_cells, BHRT_GATHER_CELLS + 1, D->d_tile_sums);
+            hipLaunchKernelGGL(k_gather_cell_scatter, grid, block, 0, D->stream, q0, cnt, D->d_cell_of, D->d_rank_of, D->d_cells, D->d_gorder);
+            HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_cells + BHRT_GATHER_CELLS, sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
+        } else { // (cell, query) pairs through a stable radix sort: no atomics, the queries of a cell stay in index order
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_cell_key<Sink>), grid, block, 0, D->stream, sink, q0, cnt, G, D->pm, radius, D->d_cell_of, D->d_rank_of);
+            size_t tb = D->sort_temp_bytes;
+            if (GatherSortPairs(D->d_cell_of, D->d_keys_out, D->d_rank_of, D->d_gorder, cnt, D->d_sort_temp, &tb, 28, D->stream) != 0) { SetError("gather sort failed"); return BHRT_ERR_HIP; }
+            hipLaunchKernelGGL(k_gather_first_out, dim3(1), dim3(1), 0, D->stream, D->d_keys_out, cnt, D->d_n_heavy + 7);
+            HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_n_heavy + 7, sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
+        }
         order = D->d_gorder;
-        HIP_CHECK(hipMemcpyAsync(D->h_n_heavy, D->d_cells + BHRT_GATHER_CELLS, sizeof(uint32_t), hipMemcpyDeviceToHost, D->stream));
         HIP_CHECK(hipStreamSynchronize(D->stream));
         n_walk = D->h_n_heavy[0];
         grid = dim3((n_walk + kBlock - 1) / kBlock);

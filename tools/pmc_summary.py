@@ -10,6 +10,8 @@ CAL_BYTES_WRITTEN = 4 * (1 << 27)
 
 
 def short(name):
+    if "rocprim" in name:  # the library radix sort of the gather's (cell, query) pairs (gather_sort.hip): counted with the cell sort
+        return "k_gather_cell_radix_sort"
     n = name.split("(")[0]
     n = n.replace("void ", "").replace("bhrt::", "")
     return n.split("<")[0]
