@@ -132,6 +132,7 @@ struct RayOrder {
     uint32_t *park_sorted; // [cap_rays] the parked ray indices in key order
     uint32_t *park_bucket; // [1 << BHRT_PARK_KEY_BITS] + tile sums behind it
     uint32_t *frame_base;  // [3 * BHRT_ORDER_SHARDS] first Shade() frame of a segment's rays (heavy class; k_order_prefix)
+    uint32_t *park_rank;   // [cap_rays] rank of ray i inside its key's bucket (what the histogram's atomic returned)
 };
 #define BHRT_PARK_CELL_BITS 6
 #define BHRT_PARK_KEY_BITS (3 * BHRT_PARK_CELL_BITS + 3)

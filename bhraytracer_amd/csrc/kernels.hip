@@ -297,7 +297,9 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest(DevScene S, PassInfo P
     if (active) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front | ((parked + 1) << 8); }
     if (kPark && parked >= 0) {
         ord.park_key[i] = key;
-        if (!kCamera) atomicAdd(&ord.park_bucket[key], 1u); // histogram of the counting sort (the host cleared it); camera rays are not sorted
+        // histogram of the counting sort (the host cleared it); what the atomic returns is the ray's rank inside its bucket: kept, it makes the scatter
+        // pass a read of the scanned histogram instead of a second round of atomics.  Camera rays are not sorted.
+        if (!kCamera) ord.park_rank[i] = atomicAdd(&ord.park_bucket[key], 1u);
     }
     if (!ord.idx) return; // public trace API: no shading order wanted (uniform)
     uint32_t cls = RC_NONE;
@@ -351,7 +353,7 @@ __global__ void __launch_bounds__(kBlock) k_park_scatter(RayOrder ord)
     __shared__ uint32_t s_seg;
     uint32_t i;
     for (uint32_t b = blockIdx.x; parked_entry(ord, b, &s_seg, i); b += gridDim.x)
-        if (i != 0xffffffffu) ord.park_sorted[atomicAdd(&ord.park_bucket[ord.park_key[i]], 1u)] = i;
+        if (i != 0xffffffffu) ord.park_sorted[ord.park_bucket[ord.park_key[i]] + ord.park_rank[i]] = i;
 }
 // The parked rays in key order, one dense workgroup per kBlock of them: resume at the mesh node, finish the scene
 // graph, file the ray under its shading class (shard = workgroup mod 32: k_trace_closest left room for that, see
@@ -1682,7 +1684,7 @@ struct DeviceState {
     uint32_t *d_order = nullptr;               // 4 * BHRT_ORDER_SHARDS * order_shard_cap (shading order, device_types.h::RayOrder)
     uint32_t order_shard_cap = 0;
     uint32_t *d_seg = nullptr;                 // seg_start[97] + seg_count[96] + mesh_start[33] + mesh_count[33] + frame_base[96]
-    uint32_t *d_park = nullptr;                // park_key[cap_rays] + park_sorted[cap_rays] + buckets + tile sums (RayOrder)
+    uint32_t *d_park = nullptr;                // park_key[cap_rays] + park_sorted[cap_rays] + park_rank[cap_rays] + buckets + tile sums (RayOrder)
     float *d_slowf = nullptr;                  // slow queue (SlowQueue): 6 * kSlowCap floats, then kSlowCap hit distances
     uint32_t *d_slowu = nullptr;               // 3 * kSlowCap, then 3 * kSlowCap hit words (node, prim, front)
     hipStream_t stream2 = nullptr;             // k_trace_slow runs here, beside the pass
@@ -1817,7 +1819,7 @@ static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, double frames_p
     // at most (all parked rays) / 32 + one workgroup more per shard -> twice the even share always fits
     D->order_shard_cap = (uint32_t)(2 * ((((cr + 1023) / 1024 + BHRT_ORDER_SHARDS - 1) / BHRT_ORDER_SHARDS) * 1024 + 1024));
     HIP_CHECK(hipMalloc(&D->d_order, (size_t)4 * BHRT_ORDER_SHARDS * D->order_shard_cap * sizeof(uint32_t)));
-    HIP_CHECK(hipMalloc(&D->d_park, (2 * cr + (1u << BHRT_PARK_KEY_BITS) + kScanBlock) * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&D->d_park, (3 * cr + (1u << BHRT_PARK_KEY_BITS) + kScanBlock) * sizeof(uint32_t)));
     D->cap_samples = cap_samples; D->cap_rays = (uint32_t)cr; D->cap_frames = (uint32_t)cf;
     if (D->d_ph_frames) { (void)hipFree(D->d_ph_frames); D->d_ph_frames = nullptr; D->ph_frames_cap = 0; }
     return BHRT_OK;
@@ -2174,7 +2176,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         ShadowQueue SQ; { float *p = D->d_shf; const size_t c = D->cap_rays; SQ.ox = p; SQ.oy = p + c; SQ.oz = p + 2 * c; SQ.dx = p + 3 * c; SQ.dy = p + 4 * c; SQ.dz = p + 5 * c; SQ.tmax = p + 6 * c; SQ.frame = D->d_shu; }
         Frames F = MakeFrames(D);
         RayOrder RO = {D->d_order, D->order_shard_cap, D->d_seg, D->d_seg + 3 * BHRT_ORDER_SHARDS + 1, D->d_seg + 6 * BHRT_ORDER_SHARDS + 1, D->d_seg + 7 * BHRT_ORDER_SHARDS + 2,
-                       D->d_park, D->d_park + D->cap_rays, D->d_park + 2 * (size_t)D->cap_rays, D->d_seg + 8 * BHRT_ORDER_SHARDS + 3};
+                       D->d_park, D->d_park + D->cap_rays, D->d_park + 3 * (size_t)D->cap_rays, D->d_seg + 8 * BHRT_ORDER_SHARDS + 3, D->d_park + 2 * (size_t)D->cap_rays};
         HIP_CHECK(hipMemsetAsync(D->d_cnt, 0, sizeof(Counters), D->stream));
         // d_samples needs no clearing: every slot of a valid pixel is written exactly once (k_shade: background of a camera
         // miss; k_combine: root frame), and k_resolve never reads the slots of edge-tile pixels outside the image
