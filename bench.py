@@ -204,6 +204,18 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
         rays_total, closest_total, samples_total = (float(x) for x in rr.tolist())
     else:
         rays_total, closest_total, samples_total = float(rays_local), float(agg["closest_rays"]), float(agg["camera_samples"])
+    # The any-hit kernels of a wave step run BESIDE the next step's closest-hit kernels (second stream, DESIGN.md 4 "Any-hit work beside the pass"):
+    # inside the timed region the kernel groups share the GPU, so their HIP-event times overlap and sum to more than the frame.  Two more frames,
+    # untimed, with that switched off give every group's time ALONE — what `roofline.frac_alone` is computed from.
+    alone = None
+    if sc.info.n_meshes > 0 and N == 1 and opts.timers >= 1 and not ctx.get("no_alone"):
+        sc.knob("shadow_overlap", 0)
+        step(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d = step().as_dict()
+        torch.cuda.synchronize()
+        alone = dict(d, ms_per_step=(time.perf_counter() - t0) * 1e3)
+        sc.knob("shadow_overlap", 1)
     found_per_query = None
     if name == "c5" and rank == 0 and N == 1:  # one more frame, untimed, with the statistics instantiation of the lane pass (7 % slower: not the timed kernel)
         sc.knob("gather_stats", 1)
@@ -247,12 +259,17 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
              "k_trace_shadow": (agg["shadow_rays"], BYTES_PER_SHADOW_RAY, agg["launches_trace_shadow"]),
              "k_shade": (agg["closest_rays"], BYTES_PER_SHADE_VERTEX, agg["wave_iterations"]),  # one k_shade per wave step (the camera step of a mesh-free scene has no trace kernel of its own)
              "k_photon_gather": (agg.get("photon_nodes_visited", 0), BYTES_PER_PHOTON_VISITED, max(1, agg["passes"]))}
-    dom = max(units, key=lambda k: k_times[k])
+    alone_keys = {"k_trace_closest": "seconds_trace_closest", "k_trace_shadow": "seconds_trace_shadow", "k_shade": "seconds_shade", "k_photon_gather": "seconds_photon_gather"}
+    # the dominant group: by the groups' times ALONE where they were measured (beside the pass the any-hit group's event time is mostly waiting for SIMDs)
+    overlapped = sc_n_meshes > 0 and os.environ.get("BHRT_SHADOW_OVERLAP", "1") != "0"
+    dom = max([k for k in units if not (overlapped and not alone and k == "k_trace_shadow")],
+              key=(lambda k: alone.get(alone_keys[k], 0.0)) if alone else (lambda k: k_times[k]))
     n_units, bpu, launches = units[dom]
     launches = max(1, launches)
     avg_launch_s = k_times[dom] / launches
     units_per_launch = n_units / launches
     achieved = bpu * units_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    alone_key = alone_keys[dom]
     prof = pmc_profile(name)
     per_kernel = {k: {"seconds": k_times[k], "units": units[k][0], "bytes_per_unit": units[k][1], "launches": units[k][2],
                       "GBps": (units[k][0] * units[k][1] / k_times[k] / 1e9) if k_times[k] > 0 else 0.0} for k in units}
@@ -282,6 +299,18 @@ def run_workload(name, steps, warmup, ctx, photons, samples_per_pass=0, timers=N
                      "note": "`bound`/`frac` are the HBM roofline the contract asks for (algorithmic bytes of SURVEY.md 8(d) over the kernel group's "
                              "HIP-event time); the scene is cache-resident and these kernels are not HBM-bound (DESIGN.md 4)"},
     }
+    if alone and alone.get(alone_key, 0) > 0:
+        # the same group with the GPU to itself (one untimed frame with the any-hit work in front of the next step instead of beside it)
+        units_alone = {"k_trace_closest": alone["closest_rays"], "k_trace_shadow": alone["shadow_rays"], "k_shade": alone["closest_rays"],
+                       "k_photon_gather": alone.get("photon_nodes_visited", 0)}[dom]
+        res["roofline"]["achieved_alone"] = bpu * units_alone / alone[alone_key] / 1e9
+        res["roofline"]["frac_alone"] = res["roofline"]["achieved_alone"] / HBM_PEAK_GBPS
+        res["roofline"]["note"] += ("; in the timed region the any-hit group of a wave step runs beside the next step's closest-hit group on a second stream, so "
+                                    "`frac` is the group's rate while it SHARES the GPU and `kernel_seconds` sum to more than the frame; `frac_alone` is the "
+                                    "same group in one untimed frame with that overlap switched off (`ms_per_step_without_overlap`)")
+        res["ms_per_step_without_overlap"] = alone["ms_per_step"]
+        res["kernel_seconds_without_overlap"] = {"k_trace_closest": alone["seconds_trace_closest"], "k_trace_shadow": alone["seconds_trace_shadow"],
+                                                 "k_shade": alone["seconds_shade"], "k_photon_gather": alone.get("seconds_photon_gather", 0.0), "other": alone["seconds_other"]}
     if dom == "k_photon_gather" and res["roofline"]["traffic"] and avg_launch_s > 0:
         # the photon map is cache-resident: 24 B per examined node is an ALGORITHMIC rate served from L2 / Infinity Cache.  `frac` is the share of
         # the HBM peak that the MEASURED traffic (FETCH_SIZE + WRITE_SIZE passes) amounts to; the algorithmic figure keeps a key of its own.
@@ -331,6 +360,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = spp x N, per-GPU work fixed (default); strong = BASELINE's spp (64; 256 for c4) split over the ranks by tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alone", action="store_true", help="skip the two untimed frames that time the kernel groups alone (any-hit work in front of the next step instead of beside it): profiling runs whose kernel statistics should hold frames of one kind only")
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip the 'configs' object (c3, c3room, c4, c5)")
     ap.add_argument("--configs", default=",".join(SIDE_CONFIGS), help="workloads reported under 'configs' (default run of the headline workload only)")
     ap.add_argument("--config-steps", type=int, default=3)
@@ -375,7 +405,7 @@ def main():
         ensure_assets()
     if N > 1:
         dist.barrier()
-    ctx = {"rank": rank, "local_rank": local_rank, "N": N, "dev": dev, "dist": dist, "rehearse": args.rehearse_on_one_gpu, "scaling": args.scaling}
+    ctx = {"rank": rank, "local_rank": local_rank, "N": N, "dev": dev, "dist": dist, "rehearse": args.rehearse_on_one_gpu, "scaling": args.scaling, "no_alone": args.no_alone}
 
     head = run_workload(args.workload, args.steps, args.warmup, ctx, args.photons, args.samples_per_pass, args.timers, extras=True)
     configs = {}
@@ -406,6 +436,9 @@ def main():
             "wave_steps_per_frame": head["wave_steps_per_frame"],
             "roofline": head["roofline"],
         }
+        for k in ("ms_per_step_without_overlap", "kernel_seconds_without_overlap"):
+            if k in head:
+                out[k] = head[k]
         if "photon" in head:
             out["photon"] = head["photon"]
         if "wall_clock_extra" in head:

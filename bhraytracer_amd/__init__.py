@@ -236,7 +236,7 @@ class Scene:
         return n.value
 
     def knob(self, name: str, value: int):
-        """Test knobs ("frame_cap", "gather_lane_budget"; 0 = off): which internal path a render takes, never its result (bhrt_scene_knob)."""
+        """Knobs ("frame_cap", "gather_lane_budget", "gather_stats", "shadow_overlap"): which internal path a render takes, never its result (bhrt_scene_knob)."""
         _check(lib().bhrt_scene_knob(self._h, name.encode(), int(value)))
 
     def photon_get(self) -> np.ndarray:

@@ -1688,6 +1688,15 @@ struct DeviceState {
     float *d_slowf = nullptr;                  // slow queue (SlowQueue): 6 * kSlowCap floats, then kSlowCap hit distances
     uint32_t *d_slowu = nullptr;               // 3 * kSlowCap, then 3 * kSlowCap hit words (node, prim, front)
     hipStream_t stream2 = nullptr;             // k_trace_slow runs here, beside the pass
+    // any-hit work of a wave step beside the next step's closest-hit work (RenderRange, knobs.shadow_overlap): its own stream, the second shadow queue,
+    // its own parked list (the RC_MESH part of a RayOrder), segment table and counters
+    hipStream_t stream3 = nullptr;
+    float *d_shf2 = nullptr;                   // 7 * cap_rays
+    uint32_t *d_shu2 = nullptr;                // cap_rays
+    uint32_t *d_order_sh = nullptr;            // BHRT_ORDER_SHARDS * order_shard_cap
+    uint32_t *d_seg_sh = nullptr;              // mesh_start[33] + mesh_count[33]
+    Counters *d_cnt_sh = nullptr;
+    hipEvent_t ev_shade = nullptr, ev_shadow[2] = {nullptr, nullptr};
     Counters *d_cnt = nullptr;
     HostCounters *h_pub = nullptr; // pinned, device-visible: written by publish_counters
     HostCounters *d_pub = nullptr; // the device's address of h_pub
@@ -1730,6 +1739,7 @@ struct DeviceState {
         int frame_cap = 0;              // knob "frame_cap": a frame pool that overflows (the retry path under test); 0 = off
         int gather_lane_budget = 0;     // knob "gather_lane_budget": photons a lane may visit before its query goes to the one-wave pass; 0 = default
         bool gather_counting_sort = false; // BHRT_GATHER_COUNTING_SORT=1: the cell order by the counting sort instead of the radix sort of pairs
+        bool shadow_overlap = true;     // BHRT_SHADOW_OVERLAP=0: the any-hit kernels of a wave step on the pass's own stream, in front of the next step
         int gather_stats = 0;           // knob "gather_stats": the lane pass counts the photons its answers are made of (bhrt_stats.photon_found), 7 % slower
         void FromEnv()
         {
@@ -1739,6 +1749,7 @@ struct DeviceState {
             debug_slow = getenv("BHRT_DEBUG_SLOW") != nullptr; debug_gather = getenv("BHRT_DEBUG_GATHER") != nullptr; debug_drain = getenv("BHRT_DEBUG_DRAIN") != nullptr;
             if (const char *e = getenv("BHRT_PHOTON_BALANCE_HOST")) balance_host = atoi(e) != 0;
             if (const char *e = getenv("BHRT_GATHER_COUNTING_SORT")) gather_counting_sort = atoi(e) != 0;
+            if (const char *e = getenv("BHRT_SHADOW_OVERLAP")) shadow_overlap = atoi(e) != 0;
         }
     } knobs;
     uint32_t *d_cells = nullptr, *d_tile_sums = nullptr;
@@ -1766,6 +1777,10 @@ void DestroyDeviceState(DeviceState *d)
     for (int k = 0; k < 2; k++) { fr(d->d_rayf[k]); fr(d->d_rayu[k]); }
     fr(d->d_hitf); fr(d->d_hiti); fr(d->d_shf); fr(d->d_shu); fr(d->d_fu); fr(d->d_fcode); fr(d->d_ff); fr(d->d_samples); fr(d->d_order); fr(d->d_park); fr(d->d_seg); fr(d->d_cnt); fr(d->d_aux);
     fr(d->d_frame_rgb); fr(d->d_frame_rad); fr(d->d_sel); fr(d->d_slowf); fr(d->d_slowu);
+    fr(d->d_shf2); fr(d->d_shu2); fr(d->d_order_sh); fr(d->d_seg_sh); fr(d->d_cnt_sh);
+    if (d->ev_shade) (void)hipEventDestroy(d->ev_shade);
+    for (int k = 0; k < 2; k++) if (d->ev_shadow[k]) (void)hipEventDestroy(d->ev_shadow[k]);
+    if (d->stream3) (void)hipStreamDestroy(d->stream3);
     fr(d->d_api_f); fr(d->d_api_i); fr(d->d_photons); fr(d->d_ph_frames); fr(d->d_scr); fr(d->d_ph_hot); fr(d->d_ph_cold); fr(d->d_ph_dbox); fr(d->d_heavy); fr(d->d_long); fr(d->d_n_heavy); fr(d->d_cell_of); fr(d->d_gorder); fr(d->d_rank_of); fr(d->d_keys_out); if (d->d_sort_temp) (void)hipFree(d->d_sort_temp); fr(d->d_cells); fr(d->d_tile_sums);
     if (d->h_n_heavy) (void)hipHostFree(d->h_n_heavy);
     if (d->h_pub) (void)hipHostFree(d->h_pub);
@@ -1798,6 +1813,7 @@ static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, double frames_p
     if (D->cap_samples >= cap_samples && D->cap_frames >= cf_wanted) return BHRT_OK;
     auto fr = [](void *p) { if (p) (void)hipFree(p); };
     for (int k = 0; k < 2; k++) { fr(D->d_rayf[k]); fr(D->d_rayu[k]); D->d_rayf[k] = nullptr; D->d_rayu[k] = nullptr; }
+    fr(D->d_shf2); fr(D->d_shu2); fr(D->d_order_sh); D->d_shf2 = nullptr; D->d_shu2 = nullptr; D->d_order_sh = nullptr;
     fr(D->d_hitf); fr(D->d_hiti); fr(D->d_shf); fr(D->d_shu); fr(D->d_fu); fr(D->d_fcode); fr(D->d_ff); fr(D->d_samples); fr(D->d_order); fr(D->d_park);
     D->d_order = nullptr; D->d_park = nullptr;
     D->d_hitf = nullptr; D->d_hiti = nullptr; D->d_shf = nullptr; D->d_shu = nullptr; D->d_fu = nullptr; D->d_fcode = nullptr; D->d_ff = nullptr; D->d_samples = nullptr;
@@ -1820,6 +1836,11 @@ static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, double frames_p
     D->order_shard_cap = (uint32_t)(2 * ((((cr + 1023) / 1024 + BHRT_ORDER_SHARDS - 1) / BHRT_ORDER_SHARDS) * 1024 + 1024));
     HIP_CHECK(hipMalloc(&D->d_order, (size_t)4 * BHRT_ORDER_SHARDS * D->order_shard_cap * sizeof(uint32_t)));
     HIP_CHECK(hipMalloc(&D->d_park, (3 * cr + (1u << BHRT_PARK_KEY_BITS) + kScanBlock) * sizeof(uint32_t)));
+    if (D->stream3) {
+        HIP_CHECK(hipMalloc(&D->d_shf2, cr * 7 * sizeof(float)));
+        HIP_CHECK(hipMalloc(&D->d_shu2, cr * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc(&D->d_order_sh, (size_t)BHRT_ORDER_SHARDS * D->order_shard_cap * sizeof(uint32_t)));
+    }
     D->cap_samples = cap_samples; D->cap_rays = (uint32_t)cr; D->cap_frames = (uint32_t)cf;
     if (D->d_ph_frames) { (void)hipFree(D->d_ph_frames); D->d_ph_frames = nullptr; D->ph_frames_cap = 0; }
     return BHRT_OK;
@@ -1832,10 +1853,10 @@ static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, double frames_p
 static uint32_t DefaultPassSamples(DeviceState *D, bool photon_map, double frames_per_sample)
 {
     const double frame_b = 116 + (photon_map ? 60 : 0);
-    const double per_sample = 2 * (72 + 16 + 32 + 40) + 12 + frames_per_sample * frame_b;
+    const double per_sample = 2 * (72 + 16 + 32 + 40 + (D->stream3 ? 32 + 8 : 0)) + 12 + frames_per_sample * frame_b;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 1u << 26;
-    const double have = (double)D->cap_samples * (2 * (72 + 16 + 32 + 40) + 12) + (double)D->cap_frames * frame_b;
+    const double have = (double)D->cap_samples * (2 * (72 + 16 + 32 + 40 + (D->stream3 ? 32 + 8 : 0)) + 12) + (double)D->cap_frames * frame_b;
     for (uint32_t p = 1u << 28; p > (1u << 22); p >>= 1)
         if ((D->cap_samples >= p && (double)D->cap_frames >= (double)p * frames_per_sample) || (double)p * per_sample <= 0.85 * ((double)free_b + have)) return p;
     return 1u << 22;
@@ -1896,12 +1917,13 @@ struct Timer {
         d->ev_free.pop_back();
         return d->ev_pool[idx];
     }
-    Timer(DeviceState *d, double *a, int level = 1) : D(d), acc(a), e0(-1), on(d->timers >= level) { if (on) (void)hipEventRecord(Get(D, e0), D->stream); }
+    hipStream_t s;
+    Timer(DeviceState *d, double *a, int level = 1, hipStream_t on_stream = nullptr) : D(d), acc(a), e0(-1), on(d->timers >= level), s(on_stream ? on_stream : d->stream) { if (on) (void)hipEventRecord(Get(D, e0), s); }
     void Stop()
     {
         if (!on) return;
         int e1;
-        (void)hipEventRecord(Get(D, e1), D->stream);
+        (void)hipEventRecord(Get(D, e1), s);
         D->ev_pending.push_back({e0, e1, acc});
     }
 };
@@ -2174,9 +2196,17 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         RayQueue Q[2] = {MakeRayQueue(D->d_rayf[0], D->d_rayu[0], D->cap_rays), MakeRayQueue(D->d_rayf[1], D->d_rayu[1], D->cap_rays)};
         HitBuf HB; HB.t = D->d_hitf; HB.node = D->d_hiti; HB.prim = D->d_hiti + D->cap_rays; HB.front = D->d_hiti + 2 * (size_t)D->cap_rays;
         ShadowQueue SQ; { float *p = D->d_shf; const size_t c = D->cap_rays; SQ.ox = p; SQ.oy = p + c; SQ.oz = p + 2 * c; SQ.dx = p + 3 * c; SQ.dy = p + 4 * c; SQ.dz = p + 5 * c; SQ.tmax = p + 6 * c; SQ.frame = D->d_shu; }
+        // Any-hit work beside the next step's closest-hit work (stream3): the shadow rays of step s are only needed by k_combine at the end of the pass, so their
+        // kernels go to a stream of their own as soon as k_shade has written them, with a shadow queue per step parity, and fill what the pass's stream leaves
+        // idle — above all the tail of every k_trace_mesh_stream launch (the longest walks of its last batch: 0.1-0.5 ms per wave step).
+        const bool sh_overlap = D->knobs.shadow_overlap && D->stream3 != nullptr && D->d_shf2 != nullptr;
+        ShadowQueue SQ2 = SQ; if (sh_overlap) { float *p = D->d_shf2; const size_t c = D->cap_rays; SQ2.ox = p; SQ2.oy = p + c; SQ2.oz = p + 2 * c; SQ2.dx = p + 3 * c; SQ2.dy = p + 4 * c; SQ2.dz = p + 5 * c; SQ2.tmax = p + 6 * c; SQ2.frame = D->d_shu2; }
+        bool sh_pending[2] = {false, false};
         Frames F = MakeFrames(D);
         RayOrder RO = {D->d_order, D->order_shard_cap, D->d_seg, D->d_seg + 3 * BHRT_ORDER_SHARDS + 1, D->d_seg + 6 * BHRT_ORDER_SHARDS + 1, D->d_seg + 7 * BHRT_ORDER_SHARDS + 2,
                        D->d_park, D->d_park + D->cap_rays, D->d_park + 3 * (size_t)D->cap_rays, D->d_seg + 8 * BHRT_ORDER_SHARDS + 3, D->d_park + 2 * (size_t)D->cap_rays};
+        RayOrder RO_sh = RO; // the parked list of the any-hit rays when they run beside the pass: only its RC_MESH part exists
+        if (sh_overlap) { RO_sh.idx = D->d_order_sh - (size_t)RC_MESH * BHRT_ORDER_SHARDS * D->order_shard_cap; RO_sh.mesh_start = D->d_seg_sh; RO_sh.mesh_count = D->d_seg_sh + BHRT_ORDER_SHARDS + 1; }
         HIP_CHECK(hipMemsetAsync(D->d_cnt, 0, sizeof(Counters), D->stream));
         // d_samples needs no clearing: every slot of a valid pixel is written exactly once (k_shade: background of a camera
         // miss; k_combine: root frame), and k_resolve never reads the slots of edge-tile pixels outside the image
@@ -2199,6 +2229,27 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         uint32_t slow_pending = 0, slow_traced = 0; // set aside so far / of those handed to k_trace_slow
         bool injected = false; // this wave step shades the rays that were set aside: their hits are there, and they were counted in their own step
         if (D->stream2) HIP_CHECK(hipStreamSynchronize(D->stream2)); // nothing of an abandoned pass still reads the queue
+        if (D->stream3) HIP_CHECK(hipStreamSynchronize(D->stream3));
+        // the any-hit kernels of the step whose counters the host has just read, on stream3 behind `after` (an event of the pass's stream)
+        int sh_wait_par = 0; uint32_t sh_wait_n = 0;
+        auto launch_any_hit = [&](hipEvent_t after) -> int {
+            if (!sh_wait_n) return BHRT_OK;
+            const int par = sh_wait_par; const uint32_t n_sh = sh_wait_n;
+            sh_wait_n = 0;
+            const ShadowQueue &sq_s = par ? SQ2 : SQ;
+            HIP_CHECK(hipStreamWaitEvent(D->stream3, after, 0));
+            Timer t(D, &st->seconds_trace_shadow, 1, D->stream3);
+            const dim3 hg((n_sh + kBlock - 1) / kBlock), hb(kBlock);
+            if (H->n_meshes > 0) {
+                hipLaunchKernelGGL(k_trace_shadow_park, hg, hb, 0, D->stream3, D->S, sq_s, n_sh, (const uint32_t *)nullptr, F.vis, RO_sh, D->d_cnt_sh);
+                hipLaunchKernelGGL(k_mesh_prefix, dim3(1), dim3(64), 0, D->stream3, D->d_cnt_sh, RO_sh);
+                hipLaunchKernelGGL(path_mode == 1 ? (ls ? k_shadow_mesh<1, true> : k_shadow_mesh<1>) : path_mode == 2 ? (ls ? k_shadow_mesh<2, true> : k_shadow_mesh<2>) : k_shadow_mesh<0>, dim3((hg.x + BHRT_ORDER_SHARDS) * (kBlock / kShadowBlock)), dim3(kShadowBlock), 0, D->stream3, D->S, sq_s, F.vis, RO_sh);
+            } else hipLaunchKernelGGL(k_trace_shadow<false>, hg, hb, 0, D->stream3, D->S, sq_s, n_sh, (const uint32_t *)nullptr, F.vis);
+            t.Stop();
+            HIP_CHECK(hipEventRecord(D->ev_shadow[par], D->stream3));
+            sh_pending[par] = true;
+            return BHRT_OK;
+        };
         while (n_cur > 0 || slow_pending > 0) {
             injected = false;
             if (n_cur == 0) {
@@ -2247,6 +2298,10 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                     }
                     auto mesh_kernel = first_step ? (path_mode == 1 ? (ls ? k_trace_mesh<true, 1, true> : k_trace_mesh<true, 1>) : path_mode == 2 ? (ls ? k_trace_mesh<true, 2, true> : k_trace_mesh<true, 2>) : k_trace_mesh<true, 0>)
                                                   : (path_mode == 1 ? k_trace_mesh<false, 1> : path_mode == 2 ? k_trace_mesh<false, 2> : k_trace_mesh<false, 0>);
+                    if (sh_wait_n) { // the last step's any-hit kernels start with this step's mesh walk: they get the SIMDs its finished waves leave
+                        HIP_CHECK(hipEventRecord(D->ev_shade, D->stream));
+                        rc = launch_any_hit(D->ev_shade); if (rc) return rc;
+                    }
                     if (!first_step && path_mode != 0 && stream_waves > 0)
                     {
 #ifdef BHRT_DEBUG_DRAIN
@@ -2281,10 +2336,14 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 const bool tex = H->n_texmaps > 0;
                 auto shade = fused ? (tex ? k_shade<true, true, true> : k_shade<true, false, true>)
                                    : first_step ? (tex ? k_shade<true, true> : k_shade<true, false>) : (tex ? k_shade<false, true> : k_shade<false, false>);
-                hipLaunchKernelGGL(shade, sg, sb, 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], SQ, F, D->d_samples, D->d_cnt, RO, D->d_pub, seq); // + n_next, n_shadow, n_frames, overflow to the host
+                const int par = (int)(pass_steps & 1u);
+                if (sh_wait_n) { HIP_CHECK(hipEventRecord(D->ev_shade, D->stream)); rc = launch_any_hit(D->ev_shade); if (rc) return rc; }
+                if (sh_overlap && sh_pending[par]) { HIP_CHECK(hipStreamWaitEvent(D->stream, D->ev_shadow[par], 0)); sh_pending[par] = false; } // the any-hit kernels of two steps ago still read this queue
+                hipLaunchKernelGGL(shade, sg, sb, 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], (sh_overlap && par) ? SQ2 : SQ, F, D->d_samples, D->d_cnt, RO, D->d_pub, seq); // + n_next, n_shadow, n_frames, overflow to the host
                 t.Stop();
+                if (sh_overlap) HIP_CHECK(hipEventRecord(D->ev_shade, D->stream));
             }
-            { // the shadow trace of this step goes out before the host has the counters: its grid covers the upper bound
+            if (!sh_overlap) { // the shadow trace of this step goes out before the host has the counters: its grid covers the upper bound
               // (<= 1 shadow ray per shaded ray, <= the queue's capacity) and the kernels read the length on the device
                 Timer t(D, &st->seconds_trace_shadow);
                 const uint32_t bound = std::min<uint32_t>(n_cur, R.cap_shadow);
@@ -2317,11 +2376,17 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             }
             const uint32_t n_sh = hc.n_shadow;
             if (n_sh) { pass_shadow += n_sh; st->launches_trace_shadow++; }
+            if (sh_overlap && n_sh) { // beside the next step, with the queue's exact length
+                sh_wait_par = (int)(pass_steps & 1u); sh_wait_n = n_sh;
+                // launched when the NEXT step's mesh walk is (below): behind an event of the pass's stream, so k_shade has ENDED and its rays are in memory for every XCD
+                if (hc.n_next == 0) { rc = launch_any_hit(D->ev_shade); if (rc) return rc; } // no next step
+            }
             frame_marks.push_back(hc.n_frames);
             n_cur = hc.n_next;
             cur ^= 1;
             pass_steps++;
         }
+        if (sh_overlap) for (int k = 0; k < 2; k++) if (sh_pending[k]) HIP_CHECK(hipStreamWaitEvent(D->stream, D->ev_shadow[k], 0)); // every visibility is in its frame before the frames are read
         if (overflow) {
             // a capacity was exceeded: redo this pass with half the pixels in the same buffers
             // (results do not depend on the pass size: every sample has its own RNG key)
@@ -2401,7 +2466,8 @@ try {
     return BHRT_OK;
 } catch (...) { return bhrt::AbiException(); }
 
-// Test knobs (tests/): "frame_cap" — a frame pool of that many Shade() frames, so that a pass overflows and is redone in halves; "gather_lane_budget" —
+// Knobs: "shadow_overlap" — 0: the any-hit kernels of a wave step run on the pass's own stream, in front of the next step (bench.py times the kernel
+// groups alone that way; same results either way).  Test knobs (tests/): "frame_cap" — a frame pool of that many Shade() frames, so that a pass overflows and is redone in halves; "gather_lane_budget" —
 // photons a lane of the gather's first pass may visit before its query is handed to a whole wave.  0 switches a knob off.  Neither changes a result,
 // and no environment variable sets them: a stray variable in a user's environment cannot send a render through the retry path.
 int bhrt_scene_knob(bhrt_scene *scene, const char *name, int value)
@@ -2412,6 +2478,7 @@ try {
     if (!strcmp(name, "frame_cap")) scene->dev->knobs.frame_cap = value;
     else if (!strcmp(name, "gather_lane_budget")) scene->dev->knobs.gather_lane_budget = value;
     else if (!strcmp(name, "gather_stats")) scene->dev->knobs.gather_stats = value;
+    else if (!strcmp(name, "shadow_overlap")) scene->dev->knobs.shadow_overlap = value != 0;
     else { SetError(std::string("knob: unknown name ") + name); return BHRT_ERR_ARG; }
     return BHRT_OK;
 } catch (...) { return bhrt::AbiException(); }
@@ -2458,6 +2525,14 @@ try {
             int lo_prio = 0, hi_prio = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
             HIP_CHECK(hipStreamCreateWithPriority(&D->stream2, hipStreamNonBlocking, hi_prio));
+            {
+                HIP_CHECK(hipStreamCreateWithPriority(&D->stream3, hipStreamNonBlocking, hi_prio));
+                HIP_CHECK(hipEventCreateWithFlags(&D->ev_shade, hipEventDisableTiming));
+                for (int k = 0; k < 2; k++) HIP_CHECK(hipEventCreateWithFlags(&D->ev_shadow[k], hipEventDisableTiming));
+                HIP_CHECK(hipMalloc(&D->d_seg_sh, (2 * BHRT_ORDER_SHARDS + 2) * sizeof(uint32_t)));
+                HIP_CHECK(hipMalloc(&D->d_cnt_sh, sizeof(Counters)));
+                HIP_CHECK(hipMemset(D->d_cnt_sh, 0, sizeof(Counters)));
+            }
         }
     }
     HIP_CHECK(hipMalloc(&D->d_seg, (11 * BHRT_ORDER_SHARDS + 3) * sizeof(uint32_t)));

@@ -142,9 +142,11 @@ int bhrt_scene_flat(const bhrt_scene *scene, const void **blob, uint64_t *bytes)
 
 /* ---- device residency ---------------------------------------------------------------------------- */
 int bhrt_scene_upload(bhrt_scene *scene, int device); /* copies the flat scene into HBM of `device`; idempotent */
-/* test knobs of an uploaded scene ("frame_cap", "gather_lane_budget"; 0 = off): they steer which internal path a render takes, never its result.
- * The library reads its development switches (BHRT_STREAM_WAVES, BHRT_FUSED_CAMERA, BHRT_NO_SLOW_QUEUE, BHRT_DEBUG_*, BHRT_PHOTON_BALANCE_HOST) from the
- * environment once, at upload; these two are not reachable from the environment at all. */
+/* knobs of an uploaded scene: they steer which internal path a render takes, never its result.  Test knobs "frame_cap", "gather_lane_budget" (0 = off) and
+ * "gather_stats"; "shadow_overlap" (default 1; 0 = the any-hit kernels of a wave step run in front of the next step on the pass's own stream instead of
+ * beside it on a second one: the kernel groups timed alone, bench.py's `frac_alone`).
+ * The library reads its development switches (BHRT_STREAM_WAVES, BHRT_FUSED_CAMERA, BHRT_NO_SLOW_QUEUE, BHRT_DEBUG_*, BHRT_PHOTON_BALANCE_HOST,
+ * BHRT_SHADOW_OVERLAP) from the environment once, at upload; the test knobs are not reachable from the environment at all. */
 int bhrt_scene_knob(bhrt_scene *scene, const char *name, int value);
 int bhrt_device_count(int *n);
 

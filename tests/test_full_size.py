@@ -263,3 +263,20 @@ def test_leaf_skip_gives_the_same_frames(gpu, load_scene, O, name, spp):
     opts.leaf_skip = 0
     g0, st0 = sc.render_samples(opts, 0, 0, sc.width, sc.height)
     assert same_bits(g0, gs) and st0.closest_rays == st.closest_rays and st0.shadow_rays == st.shadow_rays
+
+
+@pytest.mark.parametrize("name,spp", [("c3_mesh", 2), ("c3_room", 2), ("c4_textured", 4)])
+def test_any_hit_work_beside_the_pass_gives_the_same_frames(gpu, load_scene, name, spp):
+    """The any-hit kernels of a wave step (GenLight::Shadow, GenLight.cpp:10-69) run on a second stream beside the next step's closest-hit kernels, with a
+    shadow queue per step parity; their visibilities are only read when the frames are folded at the end of the pass.  Knob "shadow_overlap" = 0 puts them
+    back in front of the next step on the pass's own stream: every sample of the whole frame has the same bits either way, and the same ray counts.  (The
+    default, overlapped path is the one every other whole-frame test compares with the oracle.)"""
+    sc = load_scene(name)
+    opts = gpu.default_opts(spp=spp, gi_bounces=3, seed=79)
+    g1, st1 = sc.render_samples(opts, 0, 0, sc.width, sc.height)
+    sc.knob("shadow_overlap", 0)
+    g0, st0 = sc.render_samples(opts, 0, 0, sc.width, sc.height)
+    sc.knob("shadow_overlap", 1)
+    g2, st2 = sc.render_samples(opts, 0, 0, sc.width, sc.height)
+    assert same_bits(g0, g1) and same_bits(g2, g1)
+    assert st0.closest_rays == st1.closest_rays == st2.closest_rays and st0.shadow_rays == st1.shadow_rays == st2.shadow_rays and st1.shadow_rays > 0

@@ -42,6 +42,12 @@ def main():
         bj = os.path.join(src, f"bench_under_rocprof_{wl}.json")
         if os.path.exists(bj):
             shutil.copy(bj, os.path.join(dst, f"{wl}_bench_under_rocprof.json"))
+        # the same run with BHRT_SHADOW_OVERLAP=0 (mesh workloads): every kernel alone on the GPU
+        for f in glob.glob(os.path.join(src, f"trace_alone_{wl}", "**", f"{wl}_kernel_stats.csv"), recursive=True):
+            shutil.copy(f, os.path.join(dst, f"{wl}_kernel_stats_alone.csv"))
+        bj = os.path.join(src, f"bench_under_rocprof_alone_{wl}.json")
+        if os.path.exists(bj):
+            shutil.copy(bj, os.path.join(dst, f"{wl}_bench_under_rocprof_alone.json"))
         # last frame timeline from the kernel trace
         for f in glob.glob(os.path.join(src, f"trace_{wl}", "**", f"{wl}_kernel_trace.csv"), recursive=True):
             rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
@@ -118,7 +124,15 @@ def main():
         except Exception:
             pass
         ktime = collections.defaultdict(float)
-        sp = os.path.join(dst, f"{wl}_kernel_stats.csv")
+        sp = os.path.join(dst, f"{wl}_kernel_stats_alone.csv")  # durations with the GPU to the kernel, like the counter passes
+        if not os.path.exists(sp):
+            sp = os.path.join(dst, f"{wl}_kernel_stats.csv")
+        else:
+            try:
+                bj3 = json.load(open(os.path.join(dst, f"{wl}_bench_under_rocprof_alone.json")))
+                frames = bj3["steps"] + bj3["warmup"] + 1
+            except Exception:
+                pass
         if os.path.exists(sp):
             for r in csv.DictReader(open(sp)):
                 ktime[short(r["Name"])] += float(r["TotalDurationNs"]) * 1e-9
