@@ -1848,8 +1848,9 @@ static int EnsureWorkspace(DeviceState *D, uint32_t cap_samples, double frames_p
 
 // The largest power of two of camera samples in flight (<= 2^28) whose wavefront buffers fit into 85 % of what the device has free, the present
 // workspace counted as free (EnsureWorkspace releases it before it allocates).  Per sample: two ray slots (72 B each: 36 B in each of the two
-// queues), their hit (16 B) and shadow (32 B) slots, shading order and park lists (40 B per ray slot), 12 B of radiance, and `frames_per_sample`
-// Shade() frames (116 B each, + 60 B with the photon map): six by default = 1.03 KB per sample, 2^27 samples = 138 GB.
+// queues), their hit (16 B) and shadow (32 B) slots, shading order and park lists (40 B per ray slot), in scenes with meshes the second shadow queue and
+// the any-hit kernels' own parked list (32 + 8 B: RenderRange, "any-hit work beside the pass"), 12 B of radiance, and `frames_per_sample`
+// Shade() frames (116 B each, + 60 B with the photon map): six by default = 1.03-1.11 KB per sample, 2^27 samples = 138-149 GB.
 static uint32_t DefaultPassSamples(DeviceState *D, bool photon_map, double frames_per_sample)
 {
     const double frame_b = 116 + (photon_map ? 60 : 0);
