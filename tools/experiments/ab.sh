@@ -3,7 +3,7 @@ VARS="$1"; WLS="${2:-c3 c3room}"
 for wl in $WLS; do
   for v in base $VARS; do
     if [ $v = base ]; then unset BHRT_LIB; else export BHRT_LIB=$PWD/bhraytracer_amd/_variants/libbhrt_$v.so; fi
-    python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-configs > gpurun_out/ab_${v}_${wl}.json 2>gpurun_out/ab_${v}_${wl}.err
+    python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-alone > gpurun_out/ab_${v}_${wl}.json 2>gpurun_out/ab_${v}_${wl}.err
     python - gpurun_out/ab_${v}_${wl}.json <<'PY'
 import json,sys
 try:
