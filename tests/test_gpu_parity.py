@@ -414,11 +414,13 @@ def test_no_jitter_no_gamma_options(gpu, load_scene, O):
     assert np.array_equal(rgb, q)
 
 
-def test_a_pass_that_overflows_its_frame_pool_is_cut_in_half_and_redone(gpu, load_scene, monkeypatch):
+@pytest.mark.parametrize("name", ["c2_glass_small", "c3_mesh_small"])
+def test_a_pass_that_overflows_its_frame_pool_is_cut_in_half_and_redone(gpu, load_scene, monkeypatch, name):
     """RenderRange's retry: k_shade flags a Shade() frame beyond the pool (cap_frames), the flag reaches the host with the step's counters
     (published by k_shade's last workgroup), the pass is redone with half the pixels — and the frame is the same, byte for byte, with
-    the statistics of the passes that completed only."""
-    sc = load_scene("c2_glass_small")
+    the statistics of the passes that completed only.  (The mesh scene: the abandoned pass has any-hit kernels of its earlier steps on the second
+    stream, and a step's any-hit rays still waiting for the next step's mesh walk.)"""
+    sc = load_scene(name)
     opts = gpu.default_opts(spp=4, gi_bounces=3, seed=9)
     base_rgb, base_rad, st = sc.render(opts)
     assert st.passes == 1
