@@ -593,9 +593,20 @@ __global__ void __launch_bounds__(64) k_trace_slow(DevScene S, SlowQueue slow, u
     if (threadIdx.x == 0) { h.t[i] = hit.t; h.node[i] = hit.node; h.prim[i] = hit.prim; h.front[i] = hit.front; }
 }
 // Files rays whose hits are already there (the slow queue, moved into the ray queue) for shading.
-__global__ void __launch_bounds__(kBlock) k_file_all(RayQueue q, HitBuf h, uint32_t n, RayOrder ord, Counters *cnt)
+// Rays [src0, src0 + m) of the slow queue with their hits (k_trace_slow) into slots [dst0, dst0 + m) of a wave step's queue
+__global__ void __launch_bounds__(kBlock) k_inject_slow(RayQueue sq, HitBuf sh, uint32_t src0, uint32_t m, RayQueue q, HitBuf h, uint32_t dst0)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t a = src0 + k, b = dst0 + k;
+    q.ox[b] = sq.ox[a]; q.oy[b] = sq.oy[a]; q.oz[b] = sq.oz[a]; q.dx[b] = sq.dx[a]; q.dy[b] = sq.dy[a]; q.dz[b] = sq.dz[a];
+    q.frame[b] = sq.frame[a]; q.meta[b] = sq.meta[a]; q.rng_ctr[b] = sq.rng_ctr[a];
+    h.t[b] = sh.t[a]; h.node[b] = sh.node[a]; h.prim[b] = sh.prim[a]; h.front[b] = sh.front[a];
+}
+// files rays [first, n) (their hits are there) under their shading classes
+__global__ void __launch_bounds__(kBlock) k_file_all(RayQueue q, HitBuf h, uint32_t first, uint32_t n, RayOrder ord, Counters *cnt)
+{
+    const uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cls = RC_NONE;
     if (i < n) {
         Hit hit;
@@ -1688,6 +1699,7 @@ struct DeviceState {
     float *d_slowf = nullptr;                  // slow queue (SlowQueue): 6 * kSlowCap floats, then kSlowCap hit distances
     uint32_t *d_slowu = nullptr;               // 3 * kSlowCap, then 3 * kSlowCap hit words (node, prim, front)
     hipStream_t stream2 = nullptr;             // k_trace_slow runs here, beside the pass
+    std::vector<hipEvent_t> slow_events;       // one per k_trace_slow launch of a pass (its hits are in place)
     // any-hit work of a wave step beside the next step's closest-hit work (RenderRange, knobs.shadow_overlap): its own stream, the second shadow queue,
     // its own parked list (the RC_MESH part of a RayOrder), segment table and counters
     hipStream_t stream3 = nullptr;
@@ -1786,6 +1798,7 @@ void DestroyDeviceState(DeviceState *d)
     if (d->h_pub) (void)hipHostFree(d->h_pub);
     for (int k = 0; k < 2; k++) if (d->ev[k]) (void)hipEventDestroy(d->ev[k]);
     for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : d->slow_events) (void)hipEventDestroy(e);
     if (d->stream2) (void)hipStreamDestroy(d->stream2);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
@@ -2227,7 +2240,13 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         const SlowQueue no_slow = {slowq.q, 0u};
         HitBuf slow_hits; slow_hits.t = D->d_slowf ? D->d_slowf + (size_t)6 * kSlowCap : nullptr; slow_hits.node = (int32_t *)(D->d_slowu ? D->d_slowu + (size_t)3 * kSlowCap : nullptr);
         slow_hits.prim = slow_hits.node ? slow_hits.node + kSlowCap : nullptr; slow_hits.front = slow_hits.node ? slow_hits.node + 2 * (size_t)kSlowCap : nullptr;
-        uint32_t slow_pending = 0, slow_traced = 0; // set aside so far / of those handed to k_trace_slow
+        uint32_t slow_pending = 0, slow_traced = 0, slow_injected = 0; // set aside so far this pass / of those handed to k_trace_slow / of those moved into a wave step
+        struct SlowBatch { uint32_t end; uint32_t step; hipEvent_t done; };
+        std::vector<SlowBatch> slow_batches; // k_trace_slow launches of this pass, in order
+        size_t slow_batch_next = 0;          // first batch not yet moved in
+        // A batch set aside by step s rides along with step s + 2 when that step is a big one (its hits, ~5 ms of walking on the second stream, are long
+        // there; the pass's stream waits for the batch's event on the device).  What is set aside late waits until the queue has run empty, as before.
+        constexpr uint32_t kInjectMinRays = 1u << 20;
         bool injected = false; // this wave step shades the rays that were set aside: their hits are there, and they were counted in their own step
         if (D->stream2) HIP_CHECK(hipStreamSynchronize(D->stream2)); // nothing of an abandoned pass still reads the queue
         if (D->stream3) HIP_CHECK(hipStreamSynchronize(D->stream3));
@@ -2251,25 +2270,34 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             sh_pending[par] = true;
             return BHRT_OK;
         };
-        while (n_cur > 0 || slow_pending > 0) {
+        while (n_cur > 0 || slow_pending > slow_injected) {
             injected = false;
+            uint32_t n_extra = 0; // slow rays that ride along with this step: slots [n_cur, n_cur + n_extra), hits in place, filed before k_shade
             if (n_cur == 0) {
                 const auto w0 = std::chrono::steady_clock::now();
                 HIP_CHECK(hipStreamSynchronize(D->stream2)); // the slow rays' hits
                 if (D->knobs.debug_slow)
                     fprintf(stderr, "slow rays: %u moved in after wave step %u, waited %.1f ms for their hits, pass time so far %.1f ms\n", slow_pending, pass_steps,
                             std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() * 1e3, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3);
-                n_cur = slow_pending;
-                for (int a = 0; a < 6; a++) HIP_CHECK(hipMemcpyAsync(D->d_rayf[cur] + (size_t)a * D->cap_rays, D->d_slowf + (size_t)a * kSlowCap, (size_t)n_cur * sizeof(float), hipMemcpyDeviceToDevice, D->stream));
-                for (int a = 0; a < 3; a++) HIP_CHECK(hipMemcpyAsync(D->d_rayu[cur] + (size_t)a * D->cap_rays, D->d_slowu + (size_t)a * kSlowCap, (size_t)n_cur * sizeof(uint32_t), hipMemcpyDeviceToDevice, D->stream));
-                HIP_CHECK(hipMemcpyAsync(HB.t, slow_hits.t, (size_t)n_cur * sizeof(float), hipMemcpyDeviceToDevice, D->stream));
-                HIP_CHECK(hipMemcpyAsync(HB.node, slow_hits.node, (size_t)n_cur * sizeof(int32_t), hipMemcpyDeviceToDevice, D->stream));
-                HIP_CHECK(hipMemcpyAsync(HB.prim, slow_hits.prim, (size_t)n_cur * sizeof(int32_t), hipMemcpyDeviceToDevice, D->stream));
-                HIP_CHECK(hipMemcpyAsync(HB.front, slow_hits.front, (size_t)n_cur * sizeof(int32_t), hipMemcpyDeviceToDevice, D->stream));
-                HIP_CHECK(hipMemsetAsync(&D->d_cnt->n_slow, 0, sizeof(uint32_t), D->stream));
+                n_cur = slow_pending - slow_injected;
+                hipLaunchKernelGGL(k_inject_slow, dim3((n_cur + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, slowq.q, slow_hits, slow_injected, n_cur, Q[cur], HB, 0u);
                 pass_deferred += n_cur;
-                slow_pending = 0; slow_traced = 0;
+                slow_injected = slow_pending;
+                slow_batch_next = slow_batches.size();
                 injected = true;
+            } else if (!first_step && n_cur >= kInjectMinRays) {
+                uint32_t upto = slow_injected;
+                size_t b = slow_batch_next;
+                while (b < slow_batches.size() && slow_batches[b].step + 2 <= pass_steps) { upto = slow_batches[b].end; b++; }
+                if (upto > slow_injected && (uint64_t)n_cur + (upto - slow_injected) <= D->cap_rays) {
+                    HIP_CHECK(hipStreamWaitEvent(D->stream, slow_batches[b - 1].done, 0)); // stream2 runs its launches in order: the last one's event covers them all
+                    n_extra = upto - slow_injected;
+                    hipLaunchKernelGGL(k_inject_slow, dim3((n_extra + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, slowq.q, slow_hits, slow_injected, n_extra, Q[cur], HB, n_cur);
+                    if (D->knobs.debug_slow) fprintf(stderr, "slow rays: %u ride along with wave step %u (%u rays)\n", n_extra, pass_steps, n_cur);
+                    pass_deferred += n_extra;
+                    slow_injected = upto;
+                    slow_batch_next = b;
+                }
             }
             const SlowQueue &sq = slowq;
             // the camera step of a scene without meshes: k_shade traces its rays itself (shade_block's kFused); BHRT_FUSED_CAMERA=0: the two-kernel form
@@ -2277,7 +2305,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             if (fused) {
             } else if (injected) {
                 Timer t(D, &st->seconds_trace_closest);
-                hipLaunchKernelGGL(k_file_all, dim3((n_cur + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, Q[cur], HB, n_cur, RO, D->d_cnt);
+                hipLaunchKernelGGL(k_file_all, dim3((n_cur + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, Q[cur], HB, 0u, n_cur, RO, D->d_cnt);
                 t.Stop();
             } else {
                 Timer t(D, &st->seconds_trace_closest);
@@ -2326,6 +2354,7 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_trace_closest<false, false, false>), tg, tb, 0, D->stream, D->S, P, Q[cur], n_cur, 0, HB, RO, D->d_cnt, no_slow);
                 t.Stop();
             }
+            if (n_extra) hipLaunchKernelGGL(k_file_all, dim3((n_extra + kBlock - 1) / kBlock), dim3(kBlock), 0, D->stream, Q[cur], HB, n_cur, n_cur + n_extra, RO, D->d_cnt);
             if (!fused) {
                 st->launches_trace_closest++;
                 hipLaunchKernelGGL(k_order_prefix, dim3(1), dim3(128), 0, D->stream, D->d_cnt, RO);
@@ -2333,21 +2362,21 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
             const uint32_t seq = ++D->pub_seq;
             {
                 Timer t(D, &st->seconds_shade, 0);
-                const dim3 sg((n_cur + kShadeBlock - 1) / kShadeBlock + (fused ? 0 : 3 * BHRT_ORDER_SHARDS)), sb(kShadeBlock);
+                const dim3 sg((n_cur + n_extra + kShadeBlock - 1) / kShadeBlock + (fused ? 0 : 3 * BHRT_ORDER_SHARDS)), sb(kShadeBlock);
                 const bool tex = H->n_texmaps > 0;
                 auto shade = fused ? (tex ? k_shade<true, true, true> : k_shade<true, false, true>)
                                    : first_step ? (tex ? k_shade<true, true> : k_shade<true, false>) : (tex ? k_shade<false, true> : k_shade<false, false>);
                 const int par = (int)(pass_steps & 1u);
                 if (sh_wait_n) { HIP_CHECK(hipEventRecord(D->ev_shade, D->stream)); rc = launch_any_hit(D->ev_shade); if (rc) return rc; }
                 if (sh_overlap && sh_pending[par]) { HIP_CHECK(hipStreamWaitEvent(D->stream, D->ev_shadow[par], 0)); sh_pending[par] = false; } // the any-hit kernels of two steps ago still read this queue
-                hipLaunchKernelGGL(shade, sg, sb, 0, D->stream, D->S, R, P, Q[cur], HB, n_cur, Q[cur ^ 1], (sh_overlap && par) ? SQ2 : SQ, F, D->d_samples, D->d_cnt, RO, D->d_pub, seq); // + n_next, n_shadow, n_frames, overflow to the host
+                hipLaunchKernelGGL(shade, sg, sb, 0, D->stream, D->S, R, P, Q[cur], HB, n_cur + n_extra, Q[cur ^ 1], (sh_overlap && par) ? SQ2 : SQ, F, D->d_samples, D->d_cnt, RO, D->d_pub, seq); // + n_next, n_shadow, n_frames, overflow to the host
                 t.Stop();
                 if (sh_overlap) HIP_CHECK(hipEventRecord(D->ev_shade, D->stream));
             }
             if (!sh_overlap) { // the shadow trace of this step goes out before the host has the counters: its grid covers the upper bound
               // (<= 1 shadow ray per shaded ray, <= the queue's capacity) and the kernels read the length on the device
                 Timer t(D, &st->seconds_trace_shadow);
-                const uint32_t bound = std::min<uint32_t>(n_cur, R.cap_shadow);
+                const uint32_t bound = std::min<uint32_t>(n_cur + n_extra, R.cap_shadow);
                 const dim3 hg((bound + kBlock - 1) / kBlock), hb(kBlock);
                 if (H->n_meshes > 0) {
                     hipLaunchKernelGGL(k_trace_shadow_park, hg, hb, 0, D->stream, D->S, SQ, bound, &D->d_cnt->n_shadow.v, F.vis, RO, D->d_cnt);
@@ -2374,6 +2403,10 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
                 hipLaunchKernelGGL(k_trace_slow, dim3(cnt_new), dim3(64), 0, D->stream2, D->S, slowq, slow_traced, slow_pending, slow_hits);
                 if (D->knobs.debug_slow) fprintf(stderr, "slow rays: %u set aside in wave step %u at %.1f ms\n", cnt_new, pass_steps, std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3);
                 slow_traced = slow_pending;
+                const size_t bi = slow_batches.size();
+                if (bi >= D->slow_events.size()) { hipEvent_t e = nullptr; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); D->slow_events.push_back(e); }
+                HIP_CHECK(hipEventRecord(D->slow_events[bi], D->stream2));
+                slow_batches.push_back({slow_pending, pass_steps, D->slow_events[bi]});
             }
             const uint32_t n_sh = hc.n_shadow;
             if (n_sh) { pass_shadow += n_sh; st->launches_trace_shadow++; }
