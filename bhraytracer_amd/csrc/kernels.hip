@@ -9,7 +9,8 @@
 //                                              Shade() entry or one refraction-chain step, emits <=2 closest rays,
 //                                              <=1 shadow ray, <=1 new shading frame (wave ballot + prefix-sum
 //                                              compaction, one atomic per workgroup and queue)
-//   k_trace_shadow  GenLight.cpp:10-69         any-hit -> visibility into the owning frame (+ _park / k_shadow_mesh with meshes)
+//   k_trace_shadow  GenLight.cpp:10-69         any-hit -> visibility into the owning frame (+ _park / k_shadow_mesh with meshes; there on a second
+//                                              stream, started with the NEXT step's mesh walk: nothing reads a visibility before k_combine)
 //   k_combine       MtlBlinn.cpp:117-137,343,431,470,511,539  folds finished frames into their parents, deepest
 //                                              wave step first (the per-level clamps forbid a running throughput)
 //   k_resolve       Main.cpp:170,220-230       in-order sample sum, /spp, gamma, Color24
