@@ -2247,7 +2247,10 @@ static int RenderRange(bhrt_scene *scene, const bhrt_opts &o, uint8_t *d_rgb8, f
         size_t slow_batch_next = 0;          // first batch not yet moved in
         // A batch set aside by step s rides along with step s + 2 when that step is a big one (its hits, ~5 ms of walking on the second stream, are long
         // there; the pass's stream waits for the batch's event on the device).  What is set aside late waits until the queue has run empty, as before.
-        constexpr uint32_t kInjectMinRays = 1u << 20;
+#ifndef BHRT_INJECT_MIN_LOG2
+#define BHRT_INJECT_MIN_LOG2 20 /* 18 / 20 / 22: C3 44.0 / 43.9 / 44.2 ms, closed room 487.6 / 486.4 / 491.1 ms */
+#endif
+        constexpr uint32_t kInjectMinRays = 1u << BHRT_INJECT_MIN_LOG2;
         bool injected = false; // this wave step shades the rays that were set aside: their hits are there, and they were counted in their own step
         if (D->stream2) HIP_CHECK(hipStreamSynchronize(D->stream2)); // nothing of an abandoned pass still reads the queue
         if (D->stream3) HIP_CHECK(hipStreamSynchronize(D->stream3));
